@@ -1,0 +1,26 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def weights_np():
+    """Synthetic state dict (seed 1234) shared by every test in the session."""
+    from audiodenoiser_amd.weights import make_state_dict
+    return make_state_dict(1234)
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN_DIR

@@ -1,0 +1,90 @@
+"""The CPU oracle against golden vectors produced by the reference's own model.py / data_loader.py.
+
+Fixtures: tests/golden/*.npz, written by tools/make_golden.py (which imports /root/reference/code).
+These tests pin the oracle; the -m gpu tests then compare the HIP path with the oracle and the goldens.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import unet_torch
+from audiodenoiser_amd.weights import make_input
+
+TAPS = oracle.TAP_NAMES
+SMALL = ((2, 16, 16), (2, 33, 47), (1, 64, 80))
+ALL = SMALL + ((1, 257, 188), (1, 513, 256))
+
+
+def _load(golden_dir, f, t):
+    g = np.load(os.path.join(golden_dir, f"unet_{f}x{t}.npz"))
+    assert int(g["weight_seed"]) == 1234 and int(g["input_seed"]) == 7
+    return g
+
+
+def _check_taps(g, taps, tol):
+    for name in TAPS:
+        a = np.asarray(taps[name], dtype=np.float64).ravel()
+        s, sa, sq, cnt = g[f"{name}_stats"]
+        assert a.size == int(cnt), name
+        scale = np.sqrt(sq / cnt)
+        got = a[g[f"{name}_idx"]]
+        assert np.abs(got - g[f"{name}_val"]).max() <= tol * max(scale, 1e-6) * 10, name
+        assert abs(np.abs(a).sum() - sa) <= tol * sa, name
+        assert abs((a * a).sum() - sq) <= 2 * tol * sq, name
+
+
+@pytest.mark.parametrize("n,f,t", SMALL)
+@pytest.mark.parametrize("acc64", [False, True])
+def test_c_oracle_matches_reference_golden(golden_dir, weights_np, n, f, t, acc64):
+    g = _load(golden_dir, f, t)
+    x = make_input(7, n, f, t)
+    y, taps = oracle.unet_forward(weights_np, x, acc64=acc64, want_taps=True)
+    ref = g["y"]
+    assert y.shape == ref.shape
+    # relative to max|y|: fp32 re-association noise of an 18-conv-deep net is ~2e-6 (measured).
+    assert np.abs(y - ref).max() <= 1e-5 * np.abs(ref).max()
+    _check_taps(g, taps, 1e-5)
+
+
+def test_c_oracle_reference_test_shape(golden_dir, weights_np):
+    """257x188 = the reference's own test-set spectrogram shape (create_test_dataset.py:39); pads in W at every level."""
+    g = _load(golden_dir, 257, 188)
+    y = oracle.unet_forward(weights_np, make_input(7, 1, 257, 188))
+    assert np.abs(y - g["y"]).max() <= 1e-5 * np.abs(g["y"]).max()
+
+
+@pytest.mark.parametrize("n,f,t", ALL)
+def test_torch_oracle_matches_reference_golden(golden_dir, weights_np, n, f, t):
+    g = _load(golden_dir, f, t)
+    sd = unet_torch.to_torch_state(weights_np)
+    y, taps = unet_torch.unet_forward(sd, torch.from_numpy(make_input(7, n, f, t)), want_taps=True)
+    ref = g["y"]
+    assert np.abs(y.numpy() - ref).max() <= 1e-6 * np.abs(ref).max()
+    _check_taps(g, {k: v.numpy() for k, v in taps.items()}, 1e-6)
+
+
+def test_oracle_rejects_too_small():
+    with pytest.raises(ValueError):
+        oracle.unet_forward({f"k{i}": np.zeros(1, np.float32) for i in range(118)}, np.zeros((1, 1, 8, 8), np.float32))
+
+
+def test_loader_quantize_pad_matches_reference(golden_dir):
+    """fp16 round trip (overflow->inf, underflow->0) + crop / bottom-right zero pad, data_loader.py:41-72."""
+    from audiodenoiser_amd.weights import hash_uniform
+    g = np.load(os.path.join(golden_dir, "loader_cases.npz"))
+    for ci in range(4):
+        shape = tuple(g[f"case{ci}_in_shape"])
+        target = tuple(g[f"case{ci}_target"])
+        u = hash_uniform(5, f"loader{ci}", 2 * shape[0] * shape[1]).reshape(2, *shape)
+        noisy = (u[0] * np.float32(8.0)).astype(np.float32)
+        clean = (u[1] * np.float32(8.0)).astype(np.float32)
+        noisy[0, 0], noisy[0, 1], noisy[0, 2], noisy[1, 0] = 70000.0, 1e-8, 3e-6, 65504.0
+        for src, key in ((noisy, "noisy"), (clean, "clean")):
+            got = oracle.quantize_pad(src, target)
+            ref = g[f"case{ci}_{key}"]
+            assert ref.shape == (1,) + target
+            assert np.array_equal(got, ref[0]), (ci, key)
+        assert np.isinf(g[f"case{ci}_noisy"][0, 0, 0]) and g[f"case{ci}_noisy"][0, 0, 1] == 0.0

@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own code in the build container.
+
+Run once here (``python tools/make_golden.py``); the reference (``/root/reference``) does not exist on
+the GPU box, so only the small outputs are committed.  Inputs and weights are NOT stored: they are
+regenerated bit-identically from ``audiodenoiser_amd.weights`` (hash PRNG) by the tests.
+
+What is frozen:
+
+* ``unet_<F>x<T>.npz`` — ``model.UNet(1,1).eval()`` (reference ``code/model.py:53-94``) loaded (strict) with
+  ``make_state_dict(seed)``, forward under ``torch.no_grad`` on ``make_input(seed_x, N, F, T)``:
+  the full output, and per block output (down1..4, bottleneck, up1..4, out) float64 statistics
+  (sum, sum|.|, sum of squares) plus 512 sampled elements at hash-chosen flat indices.
+* ``loader_cases.npz`` — ``data_loader.SpectrogramDataset`` (reference ``code/data_loader.py:37-72``) run on
+  temporary .npy files: fp16 round trip + crop/pad for four (shape, target_size) cases.
+"""
+from __future__ import annotations
+
+import contextlib
+import io
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference/code")
+
+from audiodenoiser_amd.weights import hash_uniform, make_input, make_state_dict  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+WEIGHT_SEED = 1234
+INPUT_SEED = 7
+UNET_CASES = ((2, 16, 16), (2, 33, 47), (1, 64, 80), (1, 257, 188), (1, 513, 256))
+N_SAMPLES = 512
+TAPS = ("down1", "down2", "down3", "down4", "bottleneck", "upconv1", "upconv2", "upconv3", "upconv4", "out")
+TAP_KEYS = ("down1", "down2", "down3", "down4", "bottleneck", "up1", "up2", "up3", "up4", "out")
+
+
+def sample_indices(name: str, numel: int) -> np.ndarray:
+    u = hash_uniform(99, "sample:" + name, N_SAMPLES).astype(np.float64)
+    return np.minimum((u * numel).astype(np.int64), numel - 1)
+
+
+def main() -> None:
+    import data_loader as ref_loader  # reference code/data_loader.py
+    import model as ref_model  # reference code/model.py
+
+    os.makedirs(GOLDEN, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(os.cpu_count() or 1)
+    net = ref_model.UNet(in_channels=1, num_classes=1)
+    sd = make_state_dict(WEIGHT_SEED)
+    net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, strict=True)
+    net.eval()
+
+    acts = {}
+
+    def hook(name):
+        def f(_mod, _inp, out):
+            acts[name] = (out[0] if isinstance(out, tuple) else out).detach()
+        return f
+
+    for mod_name in ("downconv1", "downconv2", "downconv3", "downconv4", "bottleneck",
+                     "upconv1", "upconv2", "upconv3", "upconv4", "out"):
+        getattr(net, mod_name).register_forward_hook(hook(mod_name))
+
+    for n, f, t in UNET_CASES:
+        x = torch.from_numpy(make_input(INPUT_SEED, n, f, t))
+        with torch.no_grad():
+            y = net(x)
+        rec = {"y": y.numpy().astype(np.float32), "shape": np.array([n, f, t]),
+               "weight_seed": np.array(WEIGHT_SEED), "input_seed": np.array(INPUT_SEED)}
+        for mod_name, key in zip(("downconv1", "downconv2", "downconv3", "downconv4", "bottleneck",
+                                  "upconv1", "upconv2", "upconv3", "upconv4", "out"), TAP_KEYS):
+            a = acts[mod_name].numpy().astype(np.float64).ravel()
+            idx = sample_indices(key, a.size)
+            rec[f"{key}_stats"] = np.array([a.sum(), np.abs(a).sum(), (a * a).sum(), a.size], dtype=np.float64)
+            rec[f"{key}_idx"] = idx
+            rec[f"{key}_val"] = a[idx].astype(np.float32)
+        path = os.path.join(GOLDEN, f"unet_{f}x{t}.npz")
+        np.savez_compressed(path, **rec)
+        print(f"wrote {path}: y{tuple(y.shape)} mean {float(y.mean()):+.4f} std {float(y.std()):.4f}")
+
+    # ---- loader cases (fp16 quantise + crop/pad), reference data_loader.SpectrogramDataset ----
+    cases = (((257, 122), (256, 64)), ((20, 30), (32, 40)), ((40, 30), (32, 40)), ((257, 188), (513, 256)))
+    rec = {}
+    for ci, (shape, target) in enumerate(cases):
+        u = hash_uniform(5, f"loader{ci}", 2 * shape[0] * shape[1]).reshape(2, *shape)
+        noisy = (u[0] * np.float32(8.0)).astype(np.float32)
+        clean = (u[1] * np.float32(8.0)).astype(np.float32)
+        # exercise fp16 overflow (> 65504 -> inf), underflow (-> 0) and subnormals
+        noisy[0, 0], noisy[0, 1], noisy[0, 2], noisy[1, 0] = 70000.0, 1e-8, 3e-6, 65504.0
+        with tempfile.TemporaryDirectory() as d:
+            np.save(os.path.join(d, "noisy_a_chunk_0.npy"), noisy)
+            np.save(os.path.join(d, "clean_a_chunk_0.npy"), clean)
+            with contextlib.redirect_stdout(io.StringIO()):
+                ds = ref_loader.SpectrogramDataset(d, target_size=target)
+            with np.errstate(over="ignore"):
+                n_t, c_t = ds[0]
+        rec[f"case{ci}_in_shape"] = np.array(shape)
+        rec[f"case{ci}_target"] = np.array(target)
+        rec[f"case{ci}_noisy"] = n_t.numpy()
+        rec[f"case{ci}_clean"] = c_t.numpy()
+    path = os.path.join(GOLDEN, "loader_cases.npz")
+    np.savez_compressed(path, **rec)
+    print("wrote", path)
+
+
+if __name__ == "__main__":
+    main()
