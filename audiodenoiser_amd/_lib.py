@@ -1,0 +1,68 @@
+"""ctypes binding of libadn.so (include/adn.h).  There is no fallback: if the HIP library cannot be loaded
+or built, every entry point raises."""
+from __future__ import annotations
+
+import ctypes
+import threading
+
+from . import build as _build
+
+_lock = threading.Lock()
+_lib = None
+
+c_float_p = ctypes.POINTER(ctypes.c_float)
+
+
+class AdnError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load (building first if the in-tree library is missing or stale) libadn.so."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        try:
+            path = _build.build()
+        except Exception as exc:  # noqa: BLE001 - re-raised with context
+            raise AdnError(f"libadn.so (MI355X HIP kernels) is missing and could not be built: {exc}") from exc
+        try:
+            L = ctypes.CDLL(path)
+        except OSError as exc:
+            raise AdnError(f"cannot load {path}: {exc}") from exc
+        vp, sz, ci, cl = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_long
+        L.adn_version.restype = ci
+        L.adn_last_error.restype = ctypes.c_char_p
+        L.adn_device_count.argtypes = [ctypes.POINTER(ci)]
+        L.adn_unet_create.argtypes = [ctypes.POINTER(vp), ci, ctypes.POINTER(c_float_p), ci]
+        L.adn_unet_destroy.argtypes = [vp]
+        L.adn_unet_workspace_bytes.argtypes = [vp, ci, ci, ci, ctypes.POINTER(sz)]
+        L.adn_unet_forward.argtypes = [vp, vp, vp, ci, ci, ci, vp, sz, vp]
+        L.adn_unet_forward_taps.argtypes = [vp, vp, vp, ci, ci, ci, vp, sz, ctypes.POINTER(vp), vp]
+        L.adn_unet_set_timing.argtypes = [vp, ci]
+        L.adn_unet_get_timing.argtypes = [vp, ci, c_float_p]
+        L.adn_stft_n_frames.argtypes = [cl, ci, ci, ci, ctypes.POINTER(cl)]
+        L.adn_stft_mag.argtypes = [vp, ci, cl, ci, ci, ci, vp, vp]
+        L.adn_quantize_pad.argtypes = [vp, ci, ci, ci, vp, ci, ci, vp]
+        L.adn_per_clip_l1.argtypes = [vp, vp, ci, cl, vp, vp]
+        for name in ("adn_device_count", "adn_unet_create", "adn_unet_destroy", "adn_unet_workspace_bytes",
+                     "adn_unet_forward", "adn_unet_forward_taps", "adn_unet_set_timing", "adn_unet_get_timing",
+                     "adn_stft_n_frames", "adn_stft_mag", "adn_quantize_pad", "adn_per_clip_l1"):
+            getattr(L, name).restype = ci
+        _lib = L
+        return L
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().adn_last_error()
+        raise AdnError(f"{what} failed (status {rc}): {msg.decode() if msg else ''}")
+
+
+EXPORTED_SYMBOLS = (
+    "adn_version", "adn_last_error", "adn_device_count", "adn_unet_create", "adn_unet_destroy",
+    "adn_unet_workspace_bytes", "adn_unet_forward", "adn_unet_forward_taps", "adn_unet_set_timing",
+    "adn_unet_get_timing", "adn_stft_n_frames", "adn_stft_mag",
+    "adn_quantize_pad", "adn_per_clip_l1",
+)

@@ -1,0 +1,509 @@
+// C ABI of libadn.so (include/adn.h): handle management, BatchNorm folding + weight packing, workspace
+// planning and the launch sequence of the U-Net forward (reference /root/reference/code/model.py:70-94).
+#include "../../include/adn.h"
+#include "adn_internal.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+int fail_hip(hipError_t e, const char *what)
+{
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return ADN_ERR_HIP;
+}
+#define ADN_HIP(call)                                   \
+    do {                                                \
+        hipError_t e_ = (call);                         \
+        if (e_ != hipSuccess) return fail_hip(e_, #call); \
+    } while (0)
+
+constexpr float BN_EPS = 1e-5f;   // nn.BatchNorm2d default (reference model.py:12,15)
+constexpr int CH[5] = {64, 128, 256, 512, 1024};
+
+struct Conv3x3Layer {
+    int Cin, Cout;
+    size_t w_off, b_off;   // float offsets into the packed device buffer
+};
+struct ConvTLayer {
+    int Cin, Cout;
+    size_t w_off, b_off;
+};
+
+}  // namespace
+
+struct adn_unet {
+    int device = 0;
+    float *dev = nullptr;          // all packed weights
+    size_t dev_floats = 0;
+    size_t first_w = 0, first_b = 0;       // Conv2d(1->64): [9][64] + bias[64]
+    Conv3x3Layer c3[17];                   // the 17 MFMA 3x3 convolutions in execution order
+    ConvTLayer ct[4];
+    size_t out_w = 0;
+    float out_b = 0.f;
+    // optional per-launch timing (adn_unet_set_timing)
+    std::vector<hipEvent_t> events;
+    int timing_max = 0, timing_count = 0;
+};
+
+namespace {
+
+// Fold eval-mode BatchNorm into the convolution in front of it:
+//   BN(conv(x)) = scale * (W*x + b - mean) + beta,  scale = gamma / sqrt(var + eps)
+void bn_fold(const float *b, const float *gamma, const float *beta, const float *mean, const float *var, int C,
+             std::vector<float> &scale, std::vector<float> &bias)
+{
+    scale.resize(C);
+    bias.resize(C);
+    for (int c = 0; c < C; ++c) {
+        const float s = gamma[c] / std::sqrt(var[c] + BN_EPS);
+        scale[c] = s;
+        bias[c] = (b[c] - mean[c]) * s + beta[c];
+    }
+}
+
+// Packed layout consumed by conv_mfma_f32 (conv_kernels.hip): [column tile][chunk][tap][kgroup][half][n][4]
+// where element kk of (kgroup s, half h) is input channel chunk*KC + 8*s + 4*h + kk.
+void pack_conv3x3(const float *w /*(Cout,Cin,3,3)*/, const std::vector<float> &scale, int Cin, int Cout, float *dst)
+{
+    const adn::ConvGeom g = adn::conv_geom(adn::CONV3X3_RELU, Cout);
+    const int BN = g.BN, KC = g.KC, KG = KC / 8;
+    const int nct = Cout / BN, nchunk = Cin / KC;
+    size_t o = 0;
+    for (int ct = 0; ct < nct; ++ct)
+        for (int ch = 0; ch < nchunk; ++ch)
+            for (int tap = 0; tap < 9; ++tap)
+                for (int s = 0; s < KG; ++s)
+                    for (int h = 0; h < 2; ++h)
+                        for (int n = 0; n < BN; ++n) {
+                            const int co = ct * BN + n;
+                            for (int kk = 0; kk < 4; ++kk) {
+                                const int ci = ch * KC + 8 * s + 4 * h + kk;
+                                dst[o++] = w[((size_t)co * Cin + ci) * 9 + tap] * scale[co];
+                            }
+                        }
+}
+
+// ConvTranspose2d(k2,s2) as a GEMM with columns col = (i*2+j)*Cout + co, K = Cin.
+void pack_convt(const float *w /*(Cin,Cout,2,2)*/, int Cin, int Cout, float *dst)
+{
+    const adn::ConvGeom g = adn::conv_geom(adn::CONVT2X2, Cout);
+    const int BN = g.BN, KC = g.KC, KG = KC / 8;
+    const int ncol = 4 * Cout, nct = ncol / BN, nchunk = Cin / KC;
+    size_t o = 0;
+    for (int ct = 0; ct < nct; ++ct)
+        for (int ch = 0; ch < nchunk; ++ch)
+            for (int s = 0; s < KG; ++s)
+                for (int h = 0; h < 2; ++h)
+                    for (int n = 0; n < BN; ++n) {
+                        const int col = ct * BN + n;
+                        const int ij = col / Cout, co = col % Cout;
+                        for (int kk = 0; kk < 4; ++kk) {
+                            const int ci = ch * KC + 8 * s + 4 * h + kk;
+                            dst[o++] = w[((size_t)ci * Cout + co) * 4 + ij];
+                        }
+                    }
+}
+
+struct Plan {
+    int N, H[5], W[5];
+    size_t tA, tB, skip[4], pool[4], total;   // float offsets
+};
+
+bool make_plan(int N, int F, int T, Plan &p)
+{
+    if (N < 1 || F < 16 || T < 16) return false;
+    p.N = N;
+    p.H[0] = F;
+    p.W[0] = T;
+    for (int l = 1; l < 5; ++l) {
+        p.H[l] = p.H[l - 1] / 2;
+        p.W[l] = p.W[l - 1] / 2;
+    }
+    size_t o = 0;
+    auto take = [&](size_t n) {
+        const size_t at = o;
+        o += (n + 63) & ~size_t(63);   // 256-byte granules
+        return at;
+    };
+    const size_t full = (size_t)N * p.H[0] * p.W[0] * 64;
+    p.tA = take(full);
+    p.tB = take(full);
+    for (int l = 0; l < 4; ++l) {
+        p.skip[l] = take((size_t)N * p.H[l] * p.W[l] * CH[l]);
+        p.pool[l] = take((size_t)N * p.H[l + 1] * p.W[l + 1] * CH[l]);
+    }
+    p.total = o;
+    return true;
+}
+
+adn::ConvArgs conv_args(const adn_unet *h, const Conv3x3Layer &L, adn::ConvKind kind, const float *in0, int C0,
+                        const float *in1, int C1, int H1, int W1, float *out, float *pool, int N, int H, int W)
+{
+    const adn::ConvGeom g = adn::conv_geom(kind, L.Cout);
+    adn::ConvArgs a;
+    a.s0 = adn::ConvSrc{in0, H, W, C0, 0, 0};
+    if (in1) {
+        const int dy = H - H1, dx = W - W1;   // F.pad(x1, [dx//2, dx-dx//2, dy//2, dy-dy//2]) (model.py:44-47)
+        a.s1 = adn::ConvSrc{in1, H1, W1, C1, dy / 2, dx / 2};
+    } else {
+        a.s1 = adn::ConvSrc{in0, 0, 0, 0, 0, 0};
+    }
+    a.nchunk0 = C0 / g.KC;
+    a.nchunk = (C0 + C1) / g.KC;
+    a.wpk = h->dev + L.w_off;
+    a.bias = h->dev + L.b_off;
+    a.out = out;
+    a.pool = pool;
+    a.N = N;
+    a.H = H;
+    a.W = W;
+    a.Cout = L.Cout;
+    a.tilesY = (H + g.TH - 1) / g.TH;
+    a.tilesX = (W + 15) / 16;
+    a.nct = L.Cout / g.BN;
+    return a;
+}
+
+int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, void *workspace, size_t ws_bytes,
+                 float *const *taps, hipStream_t st)
+{
+    if (!h || !x || !y) return fail(ADN_ERR_INVALID, "adn_unet_forward: null handle/x/y");
+    Plan p;
+    if (!make_plan(N, F, T, p)) return fail(ADN_ERR_INVALID, "adn_unet_forward: need N>=1 and F,T>=16");
+    if (!workspace || ws_bytes < p.total * sizeof(float))
+        return fail(ADN_ERR_WORKSPACE, "adn_unet_forward: workspace too small (see adn_unet_workspace_bytes)");
+    int cur_dev = -1;
+    ADN_HIP(hipGetDevice(&cur_dev));
+    if (cur_dev != h->device) ADN_HIP(hipSetDevice(h->device));
+
+    float *ws = static_cast<float *>(workspace);
+    float *tA = ws + p.tA, *tB = ws + p.tB;
+    // timing hook: events[slot*(L+1) + k] is recorded before launch k (k = L: after the last one)
+    const bool timed = h->timing_max > 0 && h->timing_count < h->timing_max && !taps;
+    hipEvent_t *ev = timed ? h->events.data() + (size_t)h->timing_count * (ADN_N_LAUNCHES + 1) : nullptr;
+    int evi = 0;
+#define ADN_MARK()                                          \
+    do {                                                    \
+        if (timed) ADN_HIP(hipEventRecord(ev[evi++], st));  \
+    } while (0)
+
+    auto export_tap = [&](int idx, const float *nhwc, int C, int Hh, int Ww) -> hipError_t {
+        if (!taps || !taps[idx]) return hipSuccess;
+        return adn::launch_nhwc_to_nchw(nhwc, taps[idx], N, Hh, Ww, C, st);
+    };
+
+    // ---- down path (model.py:72-79) ----
+    ADN_MARK();
+    ADN_HIP(adn::launch_conv_first(x, h->dev + h->first_w, h->dev + h->first_b, tA, N, p.H[0], p.W[0], st));
+    int li = 0;
+    const float *cur = tA;
+    for (int l = 0; l < 4; ++l) {
+        float *skip = ws + p.skip[l], *pool = ws + p.pool[l];
+        if (l > 0) {
+            adn::ConvArgs a = conv_args(h, h->c3[li], adn::CONV3X3_RELU, ws + p.pool[l - 1], CH[l - 1], nullptr, 0, 0, 0,
+                                        tA, nullptr, N, p.H[l], p.W[l]);
+            ADN_MARK();
+            ADN_HIP(adn::launch_conv_mfma(adn::CONV3X3_RELU, a, st));
+            ++li;
+            cur = tA;
+        }
+        adn::ConvArgs a = conv_args(h, h->c3[li], adn::CONV3X3_RELU_POOL, cur, CH[l], nullptr, 0, 0, 0, skip, pool, N,
+                                    p.H[l], p.W[l]);
+        ADN_MARK();
+        ADN_HIP(adn::launch_conv_mfma(adn::CONV3X3_RELU_POOL, a, st));
+        ++li;
+        ADN_HIP(export_tap(l, skip, CH[l], p.H[l], p.W[l]));
+    }
+    // ---- bottleneck (model.py:81) ----
+    {
+        adn::ConvArgs a = conv_args(h, h->c3[li], adn::CONV3X3_RELU, ws + p.pool[3], 512, nullptr, 0, 0, 0, tA, nullptr, N,
+                                    p.H[4], p.W[4]);
+        ADN_MARK();
+        ADN_HIP(adn::launch_conv_mfma(adn::CONV3X3_RELU, a, st));
+        ++li;
+        adn::ConvArgs b = conv_args(h, h->c3[li], adn::CONV3X3_RELU, tA, 1024, nullptr, 0, 0, 0, tB, nullptr, N, p.H[4],
+                                    p.W[4]);
+        ADN_MARK();
+        ADN_HIP(adn::launch_conv_mfma(adn::CONV3X3_RELU, b, st));
+        ++li;
+        ADN_HIP(export_tap(4, tB, 1024, p.H[4], p.W[4]));
+    }
+    // ---- up path (model.py:84-91): convT -> (virtual) pad + cat([skip, up]) -> DoubleConv ----
+    float *X = tB, *Y = tA;   // X holds the current tensor
+    int uh = p.H[4], uw = p.W[4], upc = 1024;
+    for (int l = 3; l >= 0; --l) {
+        const int co = CH[l];
+        const ConvTLayer &TL = h->ct[3 - l];
+        const adn::ConvGeom g = adn::conv_geom(adn::CONVT2X2, co);
+        adn::ConvArgs t;
+        t.s0 = adn::ConvSrc{X, uh, uw, upc, 0, 0};
+        t.s1 = adn::ConvSrc{X, 0, 0, 0, 0, 0};
+        t.nchunk0 = t.nchunk = upc / g.KC;
+        t.wpk = h->dev + TL.w_off;
+        t.bias = h->dev + TL.b_off;
+        t.out = Y;
+        t.pool = nullptr;
+        t.N = N;
+        t.H = uh;
+        t.W = uw;
+        t.Cout = co;
+        t.tilesY = (uh + g.TH - 1) / g.TH;
+        t.tilesX = (uw + 15) / 16;
+        t.nct = 4 * co / g.BN;
+        ADN_MARK();
+        ADN_HIP(adn::launch_conv_mfma(adn::CONVT2X2, t, st));
+        // first conv of the DoubleConv reads cat([skip, x1]) virtually
+        adn::ConvArgs a = conv_args(h, h->c3[li], adn::CONV3X3_RELU, ws + p.skip[l], co, Y, co, 2 * uh, 2 * uw, X, nullptr,
+                                    N, p.H[l], p.W[l]);
+        ADN_MARK();
+        ADN_HIP(adn::launch_conv_mfma(adn::CONV3X3_RELU, a, st));
+        ++li;
+        adn::ConvArgs b = conv_args(h, h->c3[li], adn::CONV3X3_RELU, X, co, nullptr, 0, 0, 0, Y, nullptr, N, p.H[l], p.W[l]);
+        ADN_MARK();
+        ADN_HIP(adn::launch_conv_mfma(adn::CONV3X3_RELU, b, st));
+        ++li;
+        ADN_HIP(export_tap(5 + (3 - l), Y, co, p.H[l], p.W[l]));
+        float *tmp = X;
+        X = Y;
+        Y = tmp;
+        uh = p.H[l];
+        uw = p.W[l];
+        upc = co;
+    }
+    // ---- 1x1 output convolution (model.py:93) ----
+    ADN_MARK();
+    ADN_HIP(adn::launch_conv_out(X, h->dev + h->out_w, h->out_b, y, (long)N * F * T, st));
+    ADN_MARK();
+    if (timed) {
+        if (evi != ADN_N_LAUNCHES + 1) return fail(ADN_ERR_INVALID, "internal: launch count mismatch");
+        ++h->timing_count;
+    }
+#undef ADN_MARK
+    if (taps && taps[9])
+        ADN_HIP(hipMemcpyAsync(taps[9], y, (size_t)N * F * T * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return ADN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int adn_version(void) { return 1; }
+
+const char *adn_last_error(void) { return g_err.c_str(); }
+
+int adn_device_count(int *count)
+{
+    if (!count) return fail(ADN_ERR_INVALID, "adn_device_count: null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail_hip(e, "hipGetDeviceCount");
+    }
+    *count = n;
+    return ADN_OK;
+}
+
+int adn_unet_create(adn_unet **handle, int device, const float *const *t, int n_tensors)
+{
+    if (!handle || !t) return fail(ADN_ERR_INVALID, "adn_unet_create: null argument");
+    if (n_tensors != ADN_N_WEIGHT_TENSORS) return fail(ADN_ERR_INVALID, "adn_unet_create: expected 118 tensors");
+    for (int i = 0; i < n_tensors; ++i)
+        if (!t[i]) return fail(ADN_ERR_INVALID, "adn_unet_create: null tensor pointer");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(ADN_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= ndev) return fail(ADN_ERR_INVALID, "adn_unet_create: bad device index");
+    ADN_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    ADN_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(ADN_ERR_NO_DEVICE, std::string("libadn is built for gfx950 only, device is ") + prop.gcnArchName);
+
+    adn_unet *h = new adn_unet();
+    h->device = device;
+    std::vector<float> host;
+    auto reserve = [&](size_t n) {
+        const size_t at = host.size();
+        host.resize(at + ((n + 63) & ~size_t(63)), 0.f);
+        return at;
+    };
+    std::vector<float> scale, bias;
+
+    // tensor table walk (state_dict order, see adn.h)
+    int ti = 0, li = 0;
+    auto add_conv3 = [&](int Cin, int Cout) {
+        bn_fold(t[ti + 1], t[ti + 2], t[ti + 3], t[ti + 4], t[ti + 5], Cout, scale, bias);
+        Conv3x3Layer &L = h->c3[li++];
+        L.Cin = Cin;
+        L.Cout = Cout;
+        L.w_off = reserve((size_t)9 * Cin * Cout);
+        pack_conv3x3(t[ti], scale, Cin, Cout, host.data() + L.w_off);
+        L.b_off = reserve(Cout);
+        std::memcpy(host.data() + L.b_off, bias.data(), sizeof(float) * Cout);
+        ti += 6;
+    };
+    // downconv1: first conv has Cin = 1 -> direct kernel, weights [tap][cout]
+    {
+        bn_fold(t[1], t[2], t[3], t[4], t[5], 64, scale, bias);
+        h->first_w = reserve(9 * 64);
+        for (int tap = 0; tap < 9; ++tap)
+            for (int co = 0; co < 64; ++co) host[h->first_w + tap * 64 + co] = t[0][co * 9 + tap] * scale[co];
+        h->first_b = reserve(64);
+        std::memcpy(host.data() + h->first_b, bias.data(), sizeof(float) * 64);
+        ti = 6;
+        add_conv3(64, 64);
+    }
+    for (int l = 1; l < 4; ++l) {
+        add_conv3(CH[l - 1], CH[l]);
+        add_conv3(CH[l], CH[l]);
+    }
+    add_conv3(512, 1024);
+    add_conv3(1024, 1024);
+    for (int l = 3; l >= 0; --l) {
+        const int cin = CH[l + 1], co = CH[l];
+        ConvTLayer &TL = h->ct[3 - l];
+        TL.Cin = cin;
+        TL.Cout = co;
+        TL.w_off = reserve((size_t)4 * cin * co);
+        pack_convt(t[ti], cin, co, host.data() + TL.w_off);
+        TL.b_off = reserve((size_t)4 * co);
+        for (int ij = 0; ij < 4; ++ij)
+            for (int c = 0; c < co; ++c) host[TL.b_off + (size_t)ij * co + c] = t[ti + 1][c];
+        ti += 2;
+        add_conv3(2 * co, co);
+        add_conv3(co, co);
+    }
+    h->out_w = reserve(64);
+    std::memcpy(host.data() + h->out_w, t[ti], sizeof(float) * 64);
+    h->out_b = t[ti + 1][0];
+    ti += 2;
+    if (ti != ADN_N_WEIGHT_TENSORS || li != 17) {
+        delete h;
+        return fail(ADN_ERR_INVALID, "adn_unet_create: internal tensor walk mismatch");
+    }
+
+    h->dev_floats = host.size();
+    hipError_t e = hipMalloc(&h->dev, host.size() * sizeof(float));
+    if (e != hipSuccess) {
+        delete h;
+        return fail_hip(e, "hipMalloc(weights)");
+    }
+    e = hipMemcpy(h->dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(h->dev);
+        delete h;
+        return fail_hip(e, "hipMemcpy(weights)");
+    }
+    *handle = h;
+    return ADN_OK;
+}
+
+int adn_unet_set_timing(adn_unet *h, int max_forwards)
+{
+    if (!h || max_forwards < 0 || max_forwards > 4096) return fail(ADN_ERR_INVALID, "adn_unet_set_timing: bad argument");
+    ADN_HIP(hipSetDevice(h->device));
+    for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
+    h->events.clear();
+    h->timing_max = 0;
+    h->timing_count = 0;
+    h->events.resize((size_t)max_forwards * (ADN_N_LAUNCHES + 1));
+    for (size_t i = 0; i < h->events.size(); ++i) ADN_HIP(hipEventCreate(&h->events[i]));
+    h->timing_max = max_forwards;
+    return ADN_OK;
+}
+
+int adn_unet_get_timing(adn_unet *h, int index, float *ms)
+{
+    if (!h || !ms || index < 0 || index >= h->timing_count) return fail(ADN_ERR_INVALID, "adn_unet_get_timing: no such forward");
+    hipEvent_t *ev = h->events.data() + (size_t)index * (ADN_N_LAUNCHES + 1);
+    ADN_HIP(hipEventSynchronize(ev[ADN_N_LAUNCHES]));
+    for (int k = 0; k < ADN_N_LAUNCHES; ++k) ADN_HIP(hipEventElapsedTime(&ms[k], ev[k], ev[k + 1]));
+    return ADN_OK;
+}
+
+int adn_unet_destroy(adn_unet *h)
+{
+    if (!h) return ADN_OK;
+    for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
+    if (h->dev) {
+        (void)hipSetDevice(h->device);
+        (void)hipFree(h->dev);
+    }
+    delete h;
+    return ADN_OK;
+}
+
+int adn_unet_workspace_bytes(const adn_unet *h, int N, int F, int T, size_t *bytes)
+{
+    (void)h;
+    if (!bytes) return fail(ADN_ERR_INVALID, "adn_unet_workspace_bytes: null");
+    Plan p;
+    if (!make_plan(N, F, T, p)) return fail(ADN_ERR_INVALID, "adn_unet_workspace_bytes: need N>=1 and F,T>=16");
+    *bytes = p.total * sizeof(float);
+    return ADN_OK;
+}
+
+int adn_unet_forward(adn_unet *h, const float *x, float *y, int N, int F, int T, void *workspace,
+                     size_t workspace_bytes, void *stream)
+{
+    return forward_impl(h, x, y, N, F, T, workspace, workspace_bytes, nullptr, static_cast<hipStream_t>(stream));
+}
+
+int adn_unet_forward_taps(adn_unet *h, const float *x, float *y, int N, int F, int T, void *workspace,
+                          size_t workspace_bytes, float *const *taps, void *stream)
+{
+    return forward_impl(h, x, y, N, F, T, workspace, workspace_bytes, taps, static_cast<hipStream_t>(stream));
+}
+
+int adn_stft_n_frames(long length, int n_fft, int hop, int center, long *n_frames)
+{
+    if (!n_frames || n_fft < 2 || hop < 1 || length < 0) return fail(ADN_ERR_INVALID, "adn_stft_n_frames: bad argument");
+    const long lp = center ? length + 2L * (n_fft / 2) : length;
+    *n_frames = lp < n_fft ? 0 : 1 + (lp - n_fft) / hop;
+    return ADN_OK;
+}
+
+int adn_stft_mag(const float *audio, int n_clips, long length, int n_fft, int hop, int center, float *out, void *stream)
+{
+    if (!audio || !out) return fail(ADN_ERR_INVALID, "adn_stft_mag: null pointer");
+    if (n_clips < 1 || hop < 1) return fail(ADN_ERR_INVALID, "adn_stft_mag: n_clips and hop must be >= 1");
+    if (n_fft < 64 || n_fft > 4096 || (n_fft & (n_fft - 1)))
+        return fail(ADN_ERR_INVALID, "adn_stft_mag: n_fft must be a power of two in [64, 4096]");
+    long nfr = 0;
+    adn_stft_n_frames(length, n_fft, hop, center, &nfr);
+    if (nfr <= 0) return fail(ADN_ERR_INVALID, "adn_stft_mag: audio shorter than n_fft");
+    hipError_t e = adn::launch_stft_mag(audio, n_clips, length, n_fft, hop, center, nfr, out,
+                                        static_cast<hipStream_t>(stream));
+    if (e == hipErrorInvalidValue) return fail(ADN_ERR_INVALID, "adn_stft_mag: hop too large for on-chip staging or grid too large");
+    if (e != hipSuccess) return fail_hip(e, "stft launch");
+    return ADN_OK;
+}
+
+int adn_quantize_pad(const float *in, int n, int h, int w, float *out, int H, int W, void *stream)
+{
+    if (!in || !out || n < 1 || h < 1 || w < 1 || H < 1 || W < 1) return fail(ADN_ERR_INVALID, "adn_quantize_pad: bad argument");
+    ADN_HIP(adn::launch_quantize_pad(in, n, h, w, out, H, W, static_cast<hipStream_t>(stream)));
+    return ADN_OK;
+}
+
+int adn_per_clip_l1(const float *a, const float *b, int n_clips, long elems_per_clip, float *out, void *stream)
+{
+    if (!a || !b || !out || n_clips < 1 || elems_per_clip < 1) return fail(ADN_ERR_INVALID, "adn_per_clip_l1: bad argument");
+    ADN_HIP(adn::launch_per_clip_l1(a, b, n_clips, elems_per_clip, out, static_cast<hipStream_t>(stream)));
+    return ADN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,56 @@
+// Internal declarations shared by the translation units of libadn.so (not part of the public ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+
+namespace adn {
+
+// One NHWC fp32 activation source of a convolution.  (offY, offX) is the zero-pad placed above / left of
+// the tensor when it is aligned to the output domain (UpSampleLayer's F.pad, reference model.py:44-47).
+struct ConvSrc {
+    const float *ptr;
+    int H, W, C;
+    int offY, offX;
+};
+
+// Arguments of the MFMA implicit-GEMM kernel (3x3 convolution or 2x2-stride-2 transposed convolution).
+struct ConvArgs {
+    ConvSrc s0, s1;        // channels [0, s0.C) come from s0, [s0.C, s0.C + s1.C) from s1 (virtual concat)
+    int nchunk0, nchunk;   // K-chunks served by s0 / in total
+    const float *wpk;      // packed weights, see pack_conv3x3 / pack_convt in adn_api.hip
+    const float *bias;     // per GEMM column (BatchNorm folded)
+    float *out;            // NHWC output
+    float *pool;           // optional 2x2 max-pooled NHWC output (EPI_RELU_POOL)
+    int N, H, W;           // tile domain: output H,W for 3x3; INPUT h,w for the transposed convolution
+    int Cout;              // output channels of the layer (GEMM columns = Cout, or 4*Cout for convT)
+    int tilesY, tilesX, nct;
+};
+
+enum ConvKind { CONV3X3_RELU = 0, CONV3X3_RELU_POOL = 1, CONVT2X2 = 2 };
+
+// Tile geometry chosen per layer (must match the weight packing).
+struct ConvGeom {
+    int TH;      // tile rows (tile is TH x 16 pixels)
+    int BN;      // GEMM columns per block
+    int KC;      // channels per K-chunk
+};
+ConvGeom conv_geom(ConvKind kind, int Cout);
+size_t conv_packed_floats_per_chunk(ConvKind kind, int Cout);   // per (column tile, chunk)
+
+hipError_t launch_conv_mfma(ConvKind kind, const ConvArgs &a, hipStream_t st);
+
+// First layer: Conv2d(1 -> 64, 3x3, pad 1) + folded BN + ReLU, NHWC output.  w9x64: [tap][cout].
+hipError_t launch_conv_first(const float *x, const float *w9x64, const float *bias, float *out,
+                             int N, int H, int W, hipStream_t st);
+// Last layer: Conv2d(64 -> 1, 1x1).
+hipError_t launch_conv_out(const float *in, const float *w64, float bias, float *out, long npix, hipStream_t st);
+// NHWC -> NCHW (parity-test export only).
+hipError_t launch_nhwc_to_nchw(const float *in, float *out, int N, int H, int W, int C, hipStream_t st);
+
+hipError_t launch_stft_mag(const float *audio, int n_clips, long L, int n_fft, int hop, int center,
+                           long n_frames, float *out, hipStream_t st);
+hipError_t launch_quantize_pad(const float *in, int n, int h, int w, float *out, int H, int W, hipStream_t st);
+hipError_t launch_per_clip_l1(const float *a, const float *b, int n_clips, long elems, float *out, hipStream_t st);
+
+}  // namespace adn

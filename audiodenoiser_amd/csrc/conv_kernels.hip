@@ -1,0 +1,375 @@
+// Convolution kernels of the U-Net forward for gfx950 (MI355X, CDNA4).
+//
+// Replaces the ATen ops behind the reference's DoubleConvLayer / DownSampleLayer / UpSampleLayer
+// (/root/reference/code/model.py:7-50): conv3x3+BatchNorm+ReLU, MaxPool2d(2), ConvTranspose2d(2,2),
+// F.pad + torch.cat, and the first (Cin=1) and last (1x1, Cout=1) convolutions (model.py:56,68).
+//
+// Layout: activations are NHWC fp32 inside the library (Cin = 1 at the entry and Cout = 1 at the exit make
+// NCHW == NHWC at the API boundary, so no transpose is ever materialised).
+//
+// conv_mfma_f32: implicit GEMM on the exact-fp32 matrix cores (v_mfma_f32_32x32x2_f32, 256 FLOP/clk/CU).
+//   GEMM rows    = pixels of a TH x 16 output tile (one 32-row MFMA block = 2 tile rows x 16 columns)
+//   GEMM columns = output channels (BN per workgroup)
+//   GEMM K       = taps x input channels, walked in chunks of KC channels: per chunk the input halo
+//                  ((TH+2) x 18 pixels x KC channels) and the 9 x KC x BN weight slab are staged in LDS once
+//                  and reused by all 9 taps — no im2col, each activation is fetched ~1.4x not 9x.
+//   K order inside an MFMA is free (A and B only have to agree), so each lane reads FOUR consecutive
+//   channels with one ds_read_b128 and feeds them to four MFMAs: lane (row r, half h) supplies channel
+//   c0 + 4h + kk at step kk.  Weights are pre-packed on the host in exactly the order the LDS image wants
+//   ([tap][kgroup][half][column][4]), so staging them is a linear copy and every B read is conflict-free.
+//   Concat + pad of the up path is virtual: a chunk is fetched from the skip tensor or from the upsampled
+//   tensor (with its pad offset) — torch.cat / F.pad never touch memory.
+//   Epilogue: folded-BN bias + ReLU, NHWC store, and (down path) the 2x2 max-pool computed in-lane from
+//   the accumulator registers (the four pixels of a pool window live in one lane by construction).
+#include "adn_internal.h"
+
+namespace adn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int TW = 16;       // tile width (pixels)
+constexpr int NTHREADS = 256;
+
+// Bijective remap so that workgroups sharing an XCD (ids congruent mod 8, observed round-robin placement)
+// work on neighbouring tiles; affects speed only, never results.
+__device__ __forceinline__ int xcd_remap(int b, int nwg)
+{
+    const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + (b >> 3);
+}
+
+template <int TH, int BN, int WM, int WN, int TAPS, int KG, int EPI>
+__global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_f32(const ConvArgs p)
+{
+    constexpr int HALO = (TAPS == 9) ? 1 : 0;
+    constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
+    constexpr int KC = 8 * KG;
+    constexpr int KQ = KC / 4;                  // float4 per pixel per chunk
+    constexpr int ASTR = KC + 4;                // LDS floats per halo pixel (+4 pad: conflict-free b128 reads)
+    constexpr int A_FLOATS = PH * PW * ASTR;
+    constexpr int B_FLOATS = TAPS * KG * 2 * BN * 4;
+    constexpr int A_ITEMS = PH * PW * KQ;
+    constexpr int A_ROUNDS = (A_ITEMS + NTHREADS - 1) / NTHREADS;
+    constexpr int B_ITEMS = B_FLOATS / 4;
+    constexpr int B_ROUNDS = (B_ITEMS + NTHREADS - 1) / NTHREADS;
+    constexpr int MB = TH * TW / 32 / WM;       // 32-row MFMA blocks per wave
+    constexpr int NB = BN / 32 / WN;            // 32-column MFMA blocks per wave
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(MB >= 1 && NB >= 1, "tile too small");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *sA = smem;
+    float *sB = smem + A_FLOATS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int hh = lane >> 5, l31 = lane & 31;
+
+    int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int ct = lid % p.nct;
+    lid /= p.nct;
+    const int tx = lid % p.tilesX;
+    lid /= p.tilesX;
+    const int ty = lid % p.tilesY;
+    const int n = lid / p.tilesY;
+    const int gy0 = ty * TH - HALO, gx0 = tx * TW - HALO;
+
+    // ---- per-thread staging plan for the halo (fixed over the chunk loop) ----
+    int aoff0[A_ROUNDS], aoff1[A_ROUNDS], alds[A_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < A_ROUNDS; ++r) {
+        const int item = tid + r * NTHREADS;
+        const int pix = item / KQ, q = item % KQ;
+        const int py = pix / PW, px = pix % PW;
+        const int gy = gy0 + py, gx = gx0 + px;
+        const bool in_range = (A_ITEMS % NTHREADS == 0) || item < A_ITEMS;
+        alds[r] = in_range ? pix * ASTR + q * 4 : -1;
+        const int y0 = gy - p.s0.offY, x0 = gx - p.s0.offX;
+        aoff0[r] = (in_range && y0 >= 0 && y0 < p.s0.H && x0 >= 0 && x0 < p.s0.W)
+                       ? (y0 * p.s0.W + x0) * p.s0.C + q * 4 : -1;
+        const int y1 = gy - p.s1.offY, x1 = gx - p.s1.offX;
+        aoff1[r] = (in_range && y1 >= 0 && y1 < p.s1.H && x1 >= 0 && x1 < p.s1.W)
+                       ? (y1 * p.s1.W + x1) * p.s1.C + q * 4 : -1;
+    }
+    const float *base0 = p.s0.ptr + (size_t)n * p.s0.H * p.s0.W * p.s0.C;
+    const float *base1 = p.s1.ptr + (size_t)n * p.s1.H * p.s1.W * p.s1.C;
+    const float *wbase = p.wpk + (size_t)ct * p.nchunk * B_FLOATS;
+
+    f32x4 ra[A_ROUNDS], rb[B_ROUNDS];
+
+#define ADN_PREFETCH(c)                                                                        \
+    do {                                                                                       \
+        const bool first_ = (c) < p.nchunk0;                                                   \
+        const float *src_ = first_ ? base0 + (c) * KC : base1 + ((c) - p.nchunk0) * KC;        \
+        _Pragma("unroll") for (int r = 0; r < A_ROUNDS; ++r) {                                 \
+            const int off_ = first_ ? aoff0[r] : aoff1[r];                                     \
+            f32x4 v_ = {0.f, 0.f, 0.f, 0.f};                                                   \
+            if (off_ >= 0) v_ = *reinterpret_cast<const f32x4 *>(src_ + off_);                 \
+            ra[r] = v_;                                                                        \
+        }                                                                                      \
+        const float *w_ = wbase + (size_t)(c) * B_FLOATS;                                      \
+        _Pragma("unroll") for (int r = 0; r < B_ROUNDS; ++r) {                                 \
+            const int item_ = tid + r * NTHREADS;                                              \
+            if ((B_ITEMS % NTHREADS == 0) || item_ < B_ITEMS)                                  \
+                rb[r] = *reinterpret_cast<const f32x4 *>(w_ + item_ * 4);                      \
+        }                                                                                      \
+    } while (0)
+
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // LDS read bases (floats)
+    const int a_lane = ((wm * MB * 2 + ((lane >> 4) & 1)) * PW + (lane & 15)) * ASTR + hh * 4;
+    const int b_lane = hh * BN * 4 + (wn * NB * 32 + l31) * 4;
+
+    ADN_PREFETCH(0);
+    for (int c = 0; c < p.nchunk; ++c) {
+        __syncthreads();   // everyone finished reading the previous chunk's LDS image
+#pragma unroll
+        for (int r = 0; r < A_ROUNDS; ++r)
+            if (alds[r] >= 0) *reinterpret_cast<f32x4 *>(sA + alds[r]) = ra[r];
+#pragma unroll
+        for (int r = 0; r < B_ROUNDS; ++r) {
+            const int item = tid + r * NTHREADS;
+            if ((B_ITEMS % NTHREADS == 0) || item < B_ITEMS)
+                *reinterpret_cast<f32x4 *>(sB + item * 4) = rb[r];
+        }
+        __syncthreads();
+        if (c + 1 < p.nchunk) ADN_PREFETCH(c + 1);   // loads stay in flight under the MFMAs below
+
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int dy = (TAPS == 9) ? tap / 3 : 0, dx = (TAPS == 9) ? tap % 3 : 0;
+#pragma unroll
+            for (int s = 0; s < KG; ++s) {
+                f32x4 a[MB], b[NB];
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+                    a[i] = *reinterpret_cast<const f32x4 *>(sA + a_lane + (i * 2 * PW + dy * PW + dx) * ASTR + s * 8);
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    b[j] = *reinterpret_cast<const f32x4 *>(sB + b_lane + j * 128 + (tap * KG + s) * 2 * BN * 4);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int i = 0; i < MB; ++i)
+#pragma unroll
+                        for (int j = 0; j < NB; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], b[j][kk], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+#undef ADN_PREFETCH
+
+    // ---- epilogue ----
+    // accumulator register r of lane (hh, l31): GEMM row m = (r&3) + 8*(r>>2) + 4*hh, column l31.
+    // row m of m-block i -> tile pixel (trow, tcol) = ((wm*MB+i)*2 + (m>>4), m&15).
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int col = ct * BN + (wn * NB + j) * 32 + l31;     // GEMM column
+        const float bv = p.bias[col];
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            const int trow0 = (wm * MB + i) * 2;
+            if (EPI == CONVT2X2) {
+                // column = (di*2+dj)*Cout + co ; output pixel (2*gy+di, 2*gx+dj); bias only, no activation.
+                const int ij = col / p.Cout, co = col - ij * p.Cout;
+                const int Ho = 2 * p.H, Wo = 2 * p.W;
+                float *ob = p.out + (size_t)n * Ho * Wo * p.Cout + co;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    const int gy = ty * TH + trow0 + (m >> 4), gx = tx * TW + (m & 15);
+                    if (gy < p.H && gx < p.W)
+                        ob[((size_t)(2 * gy + (ij >> 1)) * Wo + (2 * gx + (ij & 1))) * p.Cout] = acc[i][j][r] + bv;
+                }
+            } else {
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc[i][j][r] + bv, 0.f);
+                float *ob = p.out + (size_t)n * p.H * p.W * p.Cout + col;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    const int gy = ty * TH + trow0 + (m >> 4), gx = tx * TW + (m & 15);
+                    if (gy < p.H && gx < p.W) ob[((size_t)gy * p.W + gx) * p.Cout] = v[r];
+                }
+                if (EPI == CONV3X3_RELU_POOL) {
+                    // 2x2 window (rows trow0, trow0+1; cols tcol, tcol+1 with tcol even) = registers
+                    // (q,pp), (q,pp+1), (q+2,pp), (q+2,pp+1) with r = 4q+pp, q in {0,1}, pp in {0,2}.
+                    const int Hp = p.H >> 1, Wp = p.W >> 1;
+                    float *pb = p.pool + (size_t)n * Hp * Wp * p.Cout + col;
+                    const int py = (ty * TH + trow0) >> 1;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int pp = 0; pp < 4; pp += 2) {
+                            const float m4 = fmaxf(fmaxf(v[4 * q + pp], v[4 * q + pp + 1]),
+                                                   fmaxf(v[4 * (q + 2) + pp], v[4 * (q + 2) + pp + 1]));
+                            const int px = ((tx * TW) >> 1) + (pp >> 1) + 2 * hh + 4 * q;
+                            if (py < Hp && px < Wp) pb[((size_t)py * Wp + px) * p.Cout] = m4;
+                        }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// First layer: Conv2d(1 -> 64, 3x3, pad 1) + folded BN + ReLU (model.py:11-13 via :56).  HBM-bound
+// (4.4 FLOP/B): 16 lanes share a pixel, each lane owns 4 output channels (float4 store, 1 KiB per wave
+// store instruction, fully coalesced); weights live in registers.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict__ x, const float *__restrict__ w9x64,
+                                                         const float *__restrict__ bias, float *__restrict__ out,
+                                                         int N, int H, int W, long npix)
+{
+    const int q = threadIdx.x & 15;       // channel group: couts 4q .. 4q+3
+    const int slot = threadIdx.x >> 4;    // 16 pixels per pass
+    f32x4 wv[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const f32x4 *>(w9x64 + t * 64 + q * 4);
+    const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + q * 4);
+    const long HW = (long)H * W;
+    for (long pix = (long)blockIdx.x * 16 + slot; pix < npix; pix += (long)gridDim.x * 16) {
+        const long n = pix / HW;
+        const int rem = (int)(pix - n * HW);
+        const int gy = rem / W, gx = rem - gy * W;
+        const float *xp = x + n * HW;
+        f32x4 a = bv;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int yy = gy + dy - 1, xx = gx + dx - 1;
+                const float v = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? xp[(long)yy * W + xx] : 0.f;
+                a += wv[dy * 3 + dx] * v;
+            }
+        a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
+        *reinterpret_cast<f32x4 *>(out + pix * 64 + q * 4) = a;
+    }
+}
+
+// Last layer: Conv2d(64 -> 1, 1x1) (model.py:68,93).  HBM-bound: 16 lanes per pixel read one float4 each
+// (1 KiB per wave load instruction), 4-step xor-shuffle reduction inside the 16-lane group.
+__global__ __launch_bounds__(256) void conv_out_kernel(const float *__restrict__ in, const float *__restrict__ w64,
+                                                       float bias, float *__restrict__ out, long npix)
+{
+    const int q = threadIdx.x & 15;
+    const int slot = threadIdx.x >> 4;
+    const f32x4 wv = *reinterpret_cast<const f32x4 *>(w64 + q * 4);
+    // every lane of a wave must reach the shuffles: iterate on a wave-uniform bound
+    const long step = (long)gridDim.x * 16;
+    for (long base = (long)blockIdx.x * 16; base < npix; base += step) {
+        const long pix = base + slot;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (pix < npix) v = *reinterpret_cast<const f32x4 *>(in + pix * 64 + q * 4);
+        float s = v.x * wv.x + v.y * wv.y + v.z * wv.z + v.w * wv.w;
+        s += __shfl_xor(s, 8, 64);
+        s += __shfl_xor(s, 4, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 1, 64);
+        if (q == 0 && pix < npix) out[pix] = s + bias;
+    }
+}
+
+// NHWC -> NCHW through a 32x33 LDS tile (parity-test export only).
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                           long HW, int C)
+{
+    __shared__ float tile[32][33];
+    const long n = blockIdx.z;
+    const long p0 = (long)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int k = ty; k < 32; k += 8) {
+        const long pp = p0 + k;
+        const int c = c0 + tx;
+        tile[k][tx] = (pp < HW && c < C) ? in[(n * HW + pp) * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k;
+        const long pp = p0 + tx;
+        if (pp < HW && c < C) out[(n * C + c) * HW + pp] = tile[tx][k];
+    }
+}
+
+template <int TH, int BN, int WM, int WN, int TAPS, int KG, int EPI>
+hipError_t launch_cfg(const ConvArgs &a, hipStream_t st)
+{
+    constexpr int HALO = (TAPS == 9) ? 1 : 0;
+    constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
+    constexpr int KC = 8 * KG;
+    constexpr size_t lds = (size_t)(PH * PW * (KC + 4) + TAPS * KG * 2 * BN * 4) * sizeof(float);
+    const long nwg = (long)a.N * a.tilesY * a.tilesX * a.nct;
+    if (nwg <= 0 || nwg > 0x7fffffffL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((conv_mfma_f32<TH, BN, WM, WN, TAPS, KG, EPI>), dim3((unsigned)nwg), dim3(NTHREADS), lds, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+ConvGeom conv_geom(ConvKind kind, int Cout)
+{
+    if (kind == CONVT2X2) return ConvGeom{8, 128, 32};
+    if (Cout == 64) return ConvGeom{16, 64, 8};
+    return ConvGeom{8, 128, 8};
+}
+
+size_t conv_packed_floats_per_chunk(ConvKind kind, int Cout)
+{
+    const ConvGeom g = conv_geom(kind, Cout);
+    const int taps = kind == CONVT2X2 ? 1 : 9;
+    return (size_t)taps * (g.KC / 8) * 2 * g.BN * 4;
+}
+
+hipError_t launch_conv_mfma(ConvKind kind, const ConvArgs &a, hipStream_t st)
+{
+    if (kind == CONVT2X2) return launch_cfg<8, 128, 2, 2, 1, 4, CONVT2X2>(a, st);
+    if (a.Cout == 64) {
+        if (kind == CONV3X3_RELU_POOL) return launch_cfg<16, 64, 4, 1, 9, 1, CONV3X3_RELU_POOL>(a, st);
+        return launch_cfg<16, 64, 4, 1, 9, 1, CONV3X3_RELU>(a, st);
+    }
+    if (kind == CONV3X3_RELU_POOL) return launch_cfg<8, 128, 2, 2, 9, 1, CONV3X3_RELU_POOL>(a, st);
+    return launch_cfg<8, 128, 2, 2, 9, 1, CONV3X3_RELU>(a, st);
+}
+
+hipError_t launch_conv_first(const float *x, const float *w9x64, const float *bias, float *out,
+                             int N, int H, int W, hipStream_t st)
+{
+    const long npix = (long)N * H * W;
+    long blocks = (npix + 15) / 16;
+    if (blocks > 256L * 32) blocks = 256L * 32;
+    hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, w9x64, bias, out, N, H, W, npix);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_out(const float *in, const float *w64, float bias, float *out, long npix, hipStream_t st)
+{
+    long blocks = (npix + 15) / 16;
+    if (blocks > 256L * 32) blocks = 256L * 32;
+    hipLaunchKernelGGL(conv_out_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, w64, bias, out, npix);
+    return hipGetLastError();
+}
+
+hipError_t launch_nhwc_to_nchw(const float *in, float *out, int N, int H, int W, int C, hipStream_t st)
+{
+    const long HW = (long)H * W;
+    dim3 grid((unsigned)((HW + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)N);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, st, in, out, HW, C);
+    return hipGetLastError();
+}
+
+}  // namespace adn

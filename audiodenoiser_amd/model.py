@@ -1,0 +1,184 @@
+"""Drop-in for the reference's ``model.py`` whose eval forward runs on hand-written HIP kernels (gfx950).
+
+Mirrors the public surface of ``/root/reference/code/model.py``: ``UNet(in_channels=1, num_classes=1)`` is an
+``nn.Module`` with the reference's exact parameter tree (136 ``state_dict`` entries, strict-loadable from a
+reference checkpoint, ``test.py:65``), and ``forward(x: (N,1,F,T) float32) -> (N,1,F,T) float32``
+(``model.py:70-94``).  The arithmetic does NOT go through ATen: ``forward`` hands raw device pointers and the
+current PyTorch-ROCm stream to ``libadn.so`` (``include/adn.h``).
+
+Scope: the inference forward — eval mode, no autograd, CUDA/ROCm tensors.  Train-mode forward
+(batch-statistics BatchNorm + backward, reference ``train.py:62-71``) and CPU tensors are outside the
+accelerated path and raise; nothing falls back silently.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .weights import DOUBLE_CONVS, UP_CONVTS
+
+__all__ = ["UNet", "DoubleConvLayer", "DownSampleLayer", "UpSampleLayer"]
+
+
+class _ParamsOnly(nn.Module):
+    """The sub-blocks only hold parameters here; the fused forward lives in :meth:`UNet.forward`."""
+
+    def forward(self, *args, **kwargs):  # pragma: no cover - guard
+        raise NotImplementedError(
+            f"{type(self).__name__} is a parameter container in audiodenoiser_amd; call UNet.forward "
+            "(the whole network runs as one fused HIP launch sequence)")
+
+
+class DoubleConvLayer(_ParamsOnly):
+    """Parameters of conv3x3-BN-ReLU-conv3x3-BN-ReLU (reference model.py:7-17): ``double_conv.{0,1,3,4}``."""
+
+    def __init__(self, in_channels: int, out_channels: int):
+        super().__init__()
+        seq = nn.Sequential()
+        widths = (in_channels, out_channels)
+        for slot, cin in zip((0, 3), widths):
+            seq.add_module(str(slot), nn.Conv2d(cin, out_channels, kernel_size=3, padding=1))
+            seq.add_module(str(slot + 1), nn.BatchNorm2d(out_channels))
+            seq.add_module(str(slot + 2), nn.ReLU(inplace=True))
+        self.double_conv = seq
+
+
+class DownSampleLayer(_ParamsOnly):
+    """Parameters of reference model.py:23-28 (``conv``; the max-pool has no state)."""
+
+    def __init__(self, in_channels: int, out_channels: int):
+        super().__init__()
+        self.pool = nn.MaxPool2d(2)
+        self.conv = DoubleConvLayer(in_channels, out_channels)
+
+
+class UpSampleLayer(_ParamsOnly):
+    """Parameters of reference model.py:35-39 (``up`` = ConvTranspose2d k2 s2, ``conv`` on 2*C channels)."""
+
+    def __init__(self, in_channels: int, out_channels: int):
+        super().__init__()
+        self.up = nn.ConvTranspose2d(in_channels, out_channels, kernel_size=2, stride=2)
+        self.conv = DoubleConvLayer(in_channels, out_channels)
+
+
+class UNet(nn.Module):
+    def __init__(self, in_channels: int = 1, num_classes: int = 1):
+        super().__init__()
+        if in_channels != 1 or num_classes != 1:
+            raise ValueError("the MI355X path implements the reference configuration UNet(1, 1) (test.py:63)")
+        for (name, cin, cout) in DOUBLE_CONVS:
+            top = name.split(".")[0]
+            if top.startswith("downconv"):
+                setattr(self, top, DownSampleLayer(cin, cout))
+            elif top == "bottleneck":
+                self.bottleneck = DoubleConvLayer(cin, cout)
+        for (name, cin, cout) in UP_CONVTS:
+            setattr(self, name.split(".")[0], UpSampleLayer(cin, cout))
+        self.out = nn.Conv2d(in_channels=64, out_channels=num_classes, kernel_size=1)
+        self._handle = None
+        self._handle_key = None
+        self._workspace = None
+
+    # ------------------------------------------------------------------ handle management
+    def _float_tensors(self):
+        return [v for k, v in self.state_dict(keep_vars=True).items() if not k.endswith("num_batches_tracked")]
+
+    def _weights_key(self, device):
+        ts = self._float_tensors()
+        return (device.index, tuple(t._version for t in ts), tuple(t.data_ptr() for t in ts))
+
+    def _release(self):
+        if self._handle is not None:
+            try:
+                _lib.load().adn_unet_destroy(self._handle)
+            finally:
+                self._handle = None
+                self._handle_key = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+    def refresh_weights(self):
+        """Force re-packing (BatchNorm fold + re-layout + upload) at the next forward."""
+        self._release()
+
+    def _ensure_handle(self, device):
+        key = self._weights_key(device)
+        if self._handle is not None and key == self._handle_key:
+            return self._handle
+        self._release()
+        L = _lib.load()
+        host = [t.detach().to("cpu", torch.float32).contiguous() for t in self._float_tensors()]
+        if len(host) != 118:
+            raise _lib.AdnError(f"unexpected parameter tree: {len(host)} float tensors, expected 118")
+        table = (_lib.c_float_p * len(host))(*[ctypes.cast(t.data_ptr(), _lib.c_float_p) for t in host])
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(L.adn_unet_create(ctypes.byref(handle), device.index, table, len(host)), "adn_unet_create")
+        self._handle = handle
+        self._handle_key = key
+        return handle
+
+    def _workspace_for(self, n, f, t, device):
+        L = _lib.load()
+        need = ctypes.c_size_t()
+        _lib.check(L.adn_unet_workspace_bytes(self._handle, n, f, t, ctypes.byref(need)), "adn_unet_workspace_bytes")
+        ws = self._workspace
+        if ws is None or ws.device != device or ws.numel() < need.value:
+            self._workspace = None   # drop the old one first
+            ws = torch.empty(need.value, dtype=torch.uint8, device=device)
+            self._workspace = ws
+        return ws
+
+    # ------------------------------------------------------------------ forward
+    def _check_input(self, x):
+        if self.training:
+            raise RuntimeError("audiodenoiser_amd.UNet: train-mode forward (batch-statistics BatchNorm + autograd, "
+                               "reference train.py:62-71) is outside the MI355X inference path; call .eval()")
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise RuntimeError("audiodenoiser_amd.UNet: the HIP forward records no autograd graph; wrap the call in "
+                               "torch.no_grad() as the reference's test.py:112 / train.py:80 do")
+        if not x.is_cuda:
+            raise RuntimeError("audiodenoiser_amd.UNet: input must live on a ROCm device (no CPU path; "
+                               "move model and input with .to('cuda'))")
+        if x.dim() != 4 or x.shape[1] != 1:
+            raise ValueError(f"expected input (N, 1, F, T), got {tuple(x.shape)}")
+        if x.shape[2] < 16 or x.shape[3] < 16:
+            raise ValueError("F and T must be >= 16 (four 2x poolings)")
+        if x.dtype != torch.float32:
+            raise TypeError("expected float32 input")
+
+    def forward(self, x: torch.Tensor, return_taps: bool = False):
+        self._check_input(x)
+        x = x.contiguous()
+        n, _, f, t = x.shape
+        dev = x.device
+        handle = self._ensure_handle(dev)
+        ws = self._workspace_for(n, f, t, dev)
+        y = torch.empty_like(x)
+        L = _lib.load()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            if not return_taps:
+                _lib.check(L.adn_unet_forward(handle, x.data_ptr(), y.data_ptr(), n, f, t, ws.data_ptr(), ws.numel(),
+                                              stream), "adn_unet_forward")
+                return y
+            names = ("down1", "down2", "down3", "down4", "bottleneck", "up1", "up2", "up3", "up4", "out")
+            ch = (64, 128, 256, 512, 1024)
+            hs, wsz = [f], [t]
+            for _ in range(4):
+                hs.append(hs[-1] // 2)
+                wsz.append(wsz[-1] // 2)
+            shapes = [(n, ch[l], hs[l], wsz[l]) for l in range(4)] + [(n, 1024, hs[4], wsz[4])]
+            shapes += [(n, ch[l], hs[l], wsz[l]) for l in (3, 2, 1, 0)] + [(n, 1, f, t)]
+            taps = [torch.empty(s, dtype=torch.float32, device=dev) for s in shapes]
+            arr = (ctypes.c_void_p * 10)(*[tp.data_ptr() for tp in taps])
+            _lib.check(L.adn_unet_forward_taps(handle, x.data_ptr(), y.data_ptr(), n, f, t, ws.data_ptr(), ws.numel(),
+                                               arr, stream), "adn_unet_forward_taps")
+            return y, dict(zip(names, taps))

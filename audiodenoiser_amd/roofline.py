@@ -1,0 +1,58 @@
+"""Algorithmic work of the forward, per kernel launch, in libadn's launch order (include/adn.h, ADN_N_LAUNCHES).
+
+FLOPs: 2*Cin*Cout*k*k*Hout*Wout per convolution (direct-convolution count, no Winograd discount).
+Bytes: every op reads its input once and writes its output once; BatchNorm/bias/ReLU are fused, the max-pool
+is written by its producer, concat and pad are virtual (192.443 GFLOP and 670.63 MB of
+fp32 activation traffic per 513x256 sample, + 124.12 MB of weights once per launch sequence).
+"""
+from __future__ import annotations
+
+PEAK_MFMA_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: 256 CU x 2.4 GHz x 256 FLOP/clk, v_mfma_f32_32x32x2_f32
+PEAK_HBM_GBS = 8000.0          # HBM3E spec; ~6.3 TB/s achievable
+
+
+def unet_launches(f: int, t: int):
+    """List of dicts (name, kind, flops, act_bytes, weight_bytes) per sample, in launch order."""
+    ch = (64, 128, 256, 512, 1024)
+    hs, ws = [f], [t]
+    for _ in range(4):
+        hs.append(hs[-1] // 2)
+        ws.append(ws[-1] // 2)
+    out = []
+
+    def conv(name, kind, cin, cout, h, w, k, pool=False, hout=None, wout=None):
+        hout = h if hout is None else hout
+        wout = w if wout is None else wout
+        flops = 2.0 * cin * cout * k * k * (hout * wout if kind != "convt" else h * w)
+        if kind == "convt":
+            flops = 2.0 * cin * cout * 4 * h * w
+        act = 4.0 * (cin * h * w + cout * hout * wout)
+        if pool:
+            act += 4.0 * cout * (h // 2) * (w // 2)
+        wb = 4.0 * (cin * cout * k * k + cout)
+        out.append(dict(name=name, kind=kind, flops=flops, act_bytes=act, weight_bytes=wb))
+
+    conv("down1.conv1", "first", 1, 64, hs[0], ws[0], 3)
+    conv("down1.conv2+pool", "conv3x3", 64, 64, hs[0], ws[0], 3, pool=True)
+    for l in range(1, 4):
+        conv(f"down{l + 1}.conv1", "conv3x3", ch[l - 1], ch[l], hs[l], ws[l], 3)
+        conv(f"down{l + 1}.conv2+pool", "conv3x3", ch[l], ch[l], hs[l], ws[l], 3, pool=True)
+    conv("bottleneck.conv1", "conv3x3", 512, 1024, hs[4], ws[4], 3)
+    conv("bottleneck.conv2", "conv3x3", 1024, 1024, hs[4], ws[4], 3)
+    uh, uw, upc = hs[4], ws[4], 1024
+    for i, l in enumerate((3, 2, 1, 0)):
+        co = ch[l]
+        conv(f"up{i + 1}.convT", "convt", upc, co, uh, uw, 2, hout=2 * uh, wout=2 * uw)
+        conv(f"up{i + 1}.conv1(cat)", "conv3x3", 2 * co, co, hs[l], ws[l], 3)
+        # the concat input is read as skip (co channels at hs[l] x ws[l]) + upsampled (co channels at 2uh x 2uw)
+        out[-1]["act_bytes"] = 4.0 * (co * hs[l] * ws[l] + co * 4 * uh * uw + co * hs[l] * ws[l])
+        conv(f"up{i + 1}.conv2", "conv3x3", co, co, hs[l], ws[l], 3)
+        uh, uw, upc = hs[l], ws[l], co
+    conv("out.conv1x1", "out", 64, 1, hs[0], ws[0], 1)
+    assert len(out) == 23
+    return out
+
+
+def totals(f: int, t: int):
+    ls = unet_launches(f, t)
+    return (sum(l["flops"] for l in ls), sum(l["act_bytes"] for l in ls), sum(l["weight_bytes"] for l in ls))

@@ -1,0 +1,66 @@
+"""STFT-magnitude helpers with the reference's call surface, computed by the fused HIP kernel.
+
+Mirrors ``audio_to_magnitude_spectrogram`` (``/root/reference/code/create_train_dataset.py:162-174``,
+``librosa.stft(..., center=False)`` + ``magphase``) and ``audio_to_spectrogram``
+(``/root/reference/code/create_test_dataset.py:35-41``, ``center=True`` with librosa 0.10's zero padding).
+Defaults are the reference's constants N_FFT=512, HOP=128 (``create_train_dataset.py:26-27``).
+numpy in -> numpy out (like the reference); CUDA tensor in -> CUDA tensor out (no host round trip).
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+N_FFT = 512
+HOP_LENGTH = 128
+
+
+def stft_n_frames(length: int, n_fft: int, hop: int, center: bool) -> int:
+    out = ctypes.c_long()
+    _lib.check(_lib.load().adn_stft_n_frames(length, n_fft, hop, 1 if center else 0, ctypes.byref(out)),
+               "adn_stft_n_frames")
+    return int(out.value)
+
+
+def stft_magnitude(audio: torch.Tensor, n_fft: int = N_FFT, hop_length: int = HOP_LENGTH,
+                   center: bool = True) -> torch.Tensor:
+    """``audio`` (L,) or (n_clips, L) float32 on a ROCm device -> (..., n_fft/2+1, n_frames) float32."""
+    if not audio.is_cuda:
+        raise RuntimeError("stft_magnitude: audio must live on a ROCm device (no CPU path)")
+    if audio.dtype != torch.float32:
+        raise TypeError("stft_magnitude: expected float32 audio")
+    single = audio.dim() == 1
+    a = (audio[None] if single else audio).contiguous()
+    if a.dim() != 2:
+        raise ValueError("stft_magnitude: audio must be (L,) or (n_clips, L)")
+    n_clips, length = a.shape
+    nfr = stft_n_frames(length, n_fft, hop_length, center)
+    if nfr <= 0:
+        raise ValueError(f"audio of {length} samples is shorter than n_fft={n_fft}")
+    out = torch.empty((n_clips, n_fft // 2 + 1, nfr), dtype=torch.float32, device=a.device)
+    stream = torch.cuda.current_stream(a.device).cuda_stream
+    with torch.cuda.device(a.device):
+        _lib.check(_lib.load().adn_stft_mag(a.data_ptr(), n_clips, length, n_fft, hop_length, 1 if center else 0,
+                                            out.data_ptr(), stream), "adn_stft_mag")
+    return out[0] if single else out
+
+
+def _dispatch(audio, n_fft, hop_length, center, device):
+    if isinstance(audio, torch.Tensor):
+        return stft_magnitude(audio, n_fft, hop_length, center)
+    a = torch.from_numpy(np.ascontiguousarray(audio, dtype=np.float32)).to(device or "cuda")
+    return stft_magnitude(a, n_fft, hop_length, center).cpu().numpy()
+
+
+def audio_to_magnitude_spectrogram(audio_1d, n_fft: int = N_FFT, hop_length: int = HOP_LENGTH, device=None):
+    """1-D audio -> (n_fft/2+1, 1 + (L - n_fft)//hop) magnitudes, no centring (train-set builder semantics)."""
+    return _dispatch(audio_1d, n_fft, hop_length, False, device)
+
+
+def audio_to_spectrogram(audio, n_fft: int = N_FFT, hop_length: int = HOP_LENGTH, device=None):
+    """1-D audio -> (n_fft/2+1, 1 + L//hop) magnitudes, centred with zero padding (test-set builder semantics)."""
+    return _dispatch(audio, n_fft, hop_length, True, device)

@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Headline benchmark: spectrogram frames/s of the U-Net forward on 513x256 fp32 batches (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = one forward of the hot path over one resident batch per GPU (BASELINE configs[1]: batch 64 of
+synthetic 513x256 fp32 spectrograms) + the per-clip L1 kernel, and for N > 1 the one RCCL all-gather of the
+per-clip values (clips shard over ranks, weights replicated, no data-path collective; weak scaling: the batch
+per GPU is fixed).  Rank 0 prints ONE JSON line; `value` = all ranks' frames / max-over-ranks time.
+
+roofline: the dominant kernel is conv_mfma_f32 (the 17 fp32-MFMA 3x3 convolutions, 95 % of the FLOPs).  Its
+launches are bracketed with hipEvents on the launch stream inside libadn (adn_unet_set_timing) during the timed
+steps; achieved = algorithmic FLOPs of those launches / their summed duration (= average FLOPs per launch /
+average launch duration), peak = 157.3 TFLOP/s (fp32 MFMA, MI355X_MICROARCH.md).  `traffic` (HBM bytes per
+launch from rocprofv3 PMC passes) is read from profiles/pmc_traffic.json when that file has been produced.
+
+cpu_baseline: the oracle's torch.nn.functional restatement of the reference forward (same ATen/oneDNN kernels
+the reference's model.py dispatches to; kind "port") timed on this host's cores on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+F_BINS, T_FRAMES = 513, 256
+
+
+def cpu_baseline(sd_np, budget_s: float = 12.0):
+    """Reference-equivalent CPU forward (oracle/unet_torch.py) on B=2 batches of 513x256, all host cores."""
+    from oracle import unet_torch
+    from audiodenoiser_amd.weights import make_input
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    torch.set_num_threads(cores)
+    sd = unet_torch.to_torch_state(sd_np)
+    b = 2
+    x = torch.from_numpy(make_input(0, b, F_BINS, T_FRAMES, scale=4.0))
+    unet_torch.unet_forward(sd, x[:1])          # warm-up (oneDNN primitive creation)
+    t0 = time.perf_counter()
+    iters = 0
+    while True:
+        unet_torch.unet_forward(sd, x)
+        iters += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or iters >= 8:
+            break
+    return {"value": round(iters * b * T_FRAMES / el, 1), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{iters} forwards of batch {b} x 513x256 fp32 ({el:.1f} s), oracle/unet_torch.py "
+                      f"(torch {torch.__version__} CPU, oneDNN), after 1 warm-up"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch-per-gpu", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from audiodenoiser_amd import _lib
+    from audiodenoiser_amd import distributed as D
+    from audiodenoiser_amd.loss import per_clip_l1
+    from audiodenoiser_amd.model import UNet
+    from audiodenoiser_amd.roofline import PEAK_HBM_GBS, PEAK_MFMA_F32_TFLOPS, unet_launches
+    from audiodenoiser_amd.weights import make_state_dict
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm device (no CPU path)")
+    rank, local_rank, world = D.init_from_env("nccl")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    sd_np = make_state_dict(1234)                                     # replicated weights, regenerated per rank
+    net = UNet(1, 1)
+    net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd_np.items()}, strict=True)
+    net = net.to(dev).eval()
+
+    b = args.batch_per_gpu
+    g = torch.Generator(device=dev).manual_seed(rank)                 # per-rank shard of the global batch
+    x = torch.rand((b, 1, F_BINS, T_FRAMES), generator=g, device=dev) * 4.0      # resident in HBM
+    target = torch.rand((b, 1, F_BINS, T_FRAMES), generator=g, device=dev) * 4.0
+
+    def step():
+        y = net(x)
+        loss = per_clip_l1(y, target)
+        return D.gather_per_clip(loss)
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            allv = step()
+        L = _lib.load()
+        _lib.check(L.adn_unet_set_timing(net._handle, args.steps), "adn_unet_set_timing")
+        D.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            allv = step()
+        torch.cuda.synchronize(dev)
+        D.barrier()
+        elapsed = time.perf_counter() - t0
+    elapsed = D.max_over_ranks(elapsed, dev)
+    assert allv.numel() == b * world and bool(torch.isfinite(allv).all())
+
+    # per-launch durations of the timed steps (events recorded on the launch stream inside libadn)
+    ms = np.zeros((args.steps, 23), dtype=np.float32)
+    for i in range(args.steps):
+        _lib.check(L.adn_unet_get_timing(net._handle, i, ms[i].ctypes.data_as(_lib.c_float_p)), "adn_unet_get_timing")
+    _lib.check(L.adn_unet_set_timing(net._handle, 0), "adn_unet_set_timing")
+    ms_mean = ms.mean(axis=0)
+
+    if rank == 0:
+        launches = unet_launches(F_BINS, T_FRAMES)
+        dom = [i for i, l in enumerate(launches) if l["kind"] == "conv3x3"]
+        dom_flops = sum(launches[i]["flops"] for i in dom) * b          # per forward of this rank
+        dom_ms = float(ms_mean[dom].sum())
+        achieved = dom_flops / (dom_ms * 1e-3) / 1e12
+        tot_flops = sum(l["flops"] for l in launches) * b
+        tot_bytes = sum(l["act_bytes"] for l in launches) * b + sum(l["weight_bytes"] for l in launches)
+        fwd_ms = float(ms_mean.sum())
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                with open(tpath) as fh:
+                    traffic = json.load(fh).get("conv_mfma_f32_bytes_per_launch")
+            except (OSError, ValueError):
+                traffic = None
+        frames = b * world * T_FRAMES * args.steps
+        out = {
+            "metric": "spectrogram frames/sec (forward), 513x256 fp32",
+            "value": round(frames / elapsed, 1),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"batch={b} per GPU synthetic 513x256 fp32 spectrograms, full U-Net forward "
+                                   "(BASELINE configs[1]) + per-clip L1" + (" + all-gather" if world > 1 else ""),
+                       "batch_per_gpu": b, "global_batch": b * world, "freq_bins": F_BINS, "frames": T_FRAMES,
+                       "parallelism": f"clips sharded over {world} rank(s), weights replicated"},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_MFMA_F32_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_F32_TFLOPS, 4), "traffic": traffic,
+                         "kernel": "conv_mfma_f32 (17 fp32-MFMA 3x3 conv launches per forward)",
+                         "flops_per_launch": round(dom_flops / len(dom), 1),
+                         "avg_launch_ms": round(dom_ms / len(dom), 4)},
+            "forward": {"kernel_ms": round(fwd_ms, 3),
+                        "tflops": round(tot_flops / (fwd_ms * 1e-3) / 1e12, 2),
+                        "frac_mfma_peak": round(tot_flops / (fwd_ms * 1e-3) / 1e12 / PEAK_MFMA_F32_TFLOPS, 4),
+                        "algorithmic_GBps": round(tot_bytes / (fwd_ms * 1e-3) / 1e9, 1),
+                        "frac_hbm_peak": round(tot_bytes / (fwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                        "per_launch_ms": {l["name"]: round(float(m), 4) for l, m in zip(launches, ms_mean)}},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(sd_np)
+        print(json.dumps(out), flush=True)
+    D.barrier()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,103 @@
+/*
+ * adn.h — C ABI of libadn.so, the MI355X (gfx950) implementation of the AudioDenoiser hot path.
+ *
+ * The reference (jimonld2000/AudioDenoiser) is pure Python and has no FFI of its own; its boundary for this
+ * path is the Python API of code/model.py, code/data_loader.py and the two STFT helpers.  Each entry point
+ * below replaces the arithmetic behind one of those Python call sites (cited per function); the Python
+ * mirror in audiodenoiser_amd/{model,stft,data_loader}.py binds them with ctypes (see INTEGRATION.md for the
+ * stub a reference maintainer would add).
+ *
+ * Conventions
+ *   - plain C types only: device pointers are raw `float*`, the stream is a `hipStream_t` passed as `void*`
+ *     (NULL = the null stream).  No torch / C++ types cross this boundary.
+ *   - every function returns an int status (ADN_OK = 0); on failure adn_last_error() returns a thread-local
+ *     message.  Nothing throws or aborts across the ABI.
+ *   - work is enqueued on the caller's stream; no function synchronises the device except
+ *     adn_unet_create / adn_unet_destroy (one-time weight upload / free).
+ *   - ownership: the caller owns every buffer it passes (x, y, audio, out, workspace); a handle owns only
+ *     its packed (BatchNorm-folded, re-laid-out) weights.
+ *   - a handle is bound to one device and is not re-entrant: one forward at a time per handle.
+ *   - there is NO CPU implementation in this library.
+ */
+#ifndef ADN_H
+#define ADN_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADN_OK 0
+#define ADN_ERR_INVALID 1      /* bad argument (shape, null pointer, unsupported size) */
+#define ADN_ERR_HIP 2          /* a HIP runtime call failed; message carries hipGetErrorString */
+#define ADN_ERR_WORKSPACE 3    /* workspace too small */
+#define ADN_ERR_NO_DEVICE 4    /* no gfx950 device visible */
+
+#define ADN_N_WEIGHT_TENSORS 118   /* state_dict float tensors (136 entries minus 18 num_batches_tracked) */
+#define ADN_N_TAPS 10              /* down1..down4, bottleneck, up1..up4, out */
+#define ADN_N_LAUNCHES 23          /* kernels per forward: first conv, 17 MFMA 3x3 convs, 4 convT, 1x1 out */
+
+typedef struct adn_unet adn_unet;
+
+/* Library / diagnostics --------------------------------------------------------------------------------- */
+int adn_version(void);
+const char *adn_last_error(void);
+int adn_device_count(int *count);
+
+/* U-Net forward: replaces UNet.forward (reference code/model.py:70-94) and everything it calls —
+ * DoubleConvLayer (model.py:7-20), DownSampleLayer (model.py:23-32), UpSampleLayer (model.py:35-50). ----- */
+
+/* Build a handle from the 118 fp32 HOST tensors of `UNet(1,1).state_dict()` in state_dict order with the
+ * num_batches_tracked entries skipped (per conv+BN pair: conv.weight, conv.bias, bn.weight, bn.bias,
+ * bn.running_mean, bn.running_var; per UpSampleLayer first up.weight, up.bias; finally out.weight, out.bias).
+ * This is the weight format of the reference checkpoint (train.py:142, test.py:65).  BatchNorm (eval mode,
+ * eps 1e-5) is folded into the preceding convolution here.  Synchronous. */
+int adn_unet_create(adn_unet **handle, int device, const float *const *host_tensors, int n_tensors);
+int adn_unet_destroy(adn_unet *handle);
+
+/* Bytes of device scratch adn_unet_forward needs for an (N,1,F,T) batch. */
+int adn_unet_workspace_bytes(const adn_unet *handle, int N, int F, int T, size_t *bytes);
+
+/* y(N,1,F,T) = UNet(x(N,1,F,T)), eval-mode semantics (BatchNorm uses running statistics), fp32.
+ * x, y, workspace: device memory on the handle's device.  F,T >= 16 (four 2x poolings). */
+int adn_unet_forward(adn_unet *handle, const float *x, float *y, int N, int F, int T,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
+/* Same, additionally exporting block outputs as NCHW fp32 device tensors for parity tests: taps[i] may be
+ * NULL (skipped) or a buffer of the block's size, i = 0..3 skip tensors down1..4 (DownSampleLayer's first
+ * return value), 4 bottleneck, 5..8 up1..4, 9 out. */
+int adn_unet_forward_taps(adn_unet *handle, const float *x, float *y, int N, int F, int T,
+                          void *workspace, size_t workspace_bytes, float *const *taps, void *stream);
+
+/* Measurement hook (bench.py's roofline object): with timing enabled every kernel launch of adn_unet_forward
+ * is bracketed by hipEventRecord on the caller's stream (events are created here, never in the forward).
+ * max_forwards = 0 disables.  adn_unet_get_timing synchronises on the events of forward number `index`
+ * (0-based since the last adn_unet_set_timing) and returns the ADN_N_LAUNCHES kernel durations in
+ * milliseconds, in launch order: conv_first; conv3x3+pool (down1); [conv3x3, conv3x3+pool] x3 (down2..4);
+ * conv3x3 x2 (bottleneck); [convT, conv3x3(cat), conv3x3] x4 (up1..4); conv1x1 out. */
+int adn_unet_set_timing(adn_unet *handle, int max_forwards);
+int adn_unet_get_timing(adn_unet *handle, int index, float *ms);
+
+/* STFT magnitude: replaces audio_to_magnitude_spectrogram (code/create_train_dataset.py:162-174,
+ * center=0) and audio_to_spectrogram (code/create_test_dataset.py:35-41, center=1), i.e.
+ * librosa.stft(y, n_fft, hop_length, center, window="hann", pad_mode="constant") + librosa.magphase. ------- */
+int adn_stft_n_frames(long length, int n_fft, int hop, int center, long *n_frames);
+/* audio (n_clips, length) fp32 -> out (n_clips, n_fft/2+1, n_frames) fp32, frame index fastest.
+ * n_fft: power of two in [64, 4096]; hop >= 1. */
+int adn_stft_mag(const float *audio, int n_clips, long length, int n_fft, int hop, int center,
+                 float *out, void *stream);
+
+/* Loader arithmetic: replaces SpectrogramDataset.__getitem__/_pad_or_truncate (code/data_loader.py:41-42,
+ * 54-72) for a batch already on the device: out(n,H,W) = fp32(fp16(in(n,h,w))) cropped / zero padded at the
+ * bottom and right. */
+int adn_quantize_pad(const float *in, int n, int h, int w, float *out, int H, int W, void *stream);
+
+/* Per-clip mean absolute error, the payload of the multi-GPU all-gather (F.l1_loss per clip, cf.
+ * code/loss.py:86):  out[i] = mean_j |a[i,j] - b[i,j]|. */
+int adn_per_clip_l1(const float *a, const float *b, int n_clips, long elems_per_clip, float *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADN_H */

@@ -1,0 +1,252 @@
+"""Parity of the HIP path (through the C ABI) against the oracle and the reference-generated goldens.
+
+Tolerances (BASELINE.json north_star: "within 1e-4 relative fp32"):
+  U-Net  : max|y - ref| <= 1e-4 * max|ref| on the output; block outputs within 1e-4 of their rms scale.
+  STFT   : max|m - ref| <= 1e-4 * max|ref| (oracle = float64 FFT rounded to fp32, librosa semantics; UNPINNED
+           at the librosa boundary, see oracle/stft_numpy.py).
+  loader : bit exact.
+Nothing here reads /root/reference: goldens are committed under tests/golden/.
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+GOLDEN_SHAPES = ((2, 16, 16), (2, 33, 47), (1, 64, 80), (1, 257, 188), (1, 513, 256))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    return torch.device("cuda", 0)
+
+
+@pytest.fixture(scope="module")
+def net(weights_np, dev):
+    from audiodenoiser_amd.model import UNet
+    m = UNet(1, 1)
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in weights_np.items()}, strict=True)
+    return m.to(dev).eval()
+
+
+def _rel(a, ref):
+    return float(np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-30))
+
+
+@pytest.mark.parametrize("n,f,t", GOLDEN_SHAPES)
+def test_unet_matches_reference_golden(net, dev, golden_dir, n, f, t):
+    from audiodenoiser_amd.weights import make_input
+    g = np.load(os.path.join(golden_dir, f"unet_{f}x{t}.npz"))
+    x = torch.from_numpy(make_input(7, n, f, t)).to(dev)
+    with torch.no_grad():
+        y, taps = net(x, return_taps=True)
+    y = y.cpu().numpy()
+    assert y.shape == g["y"].shape
+    assert _rel(y, g["y"]) <= TOL
+    for name, tp in taps.items():
+        a = tp.cpu().numpy().astype(np.float64).ravel()
+        s, sa, sq, cnt = g[f"{name}_stats"]
+        assert a.size == int(cnt), name
+        rms = np.sqrt(sq / cnt)
+        assert np.abs(a[g[f"{name}_idx"]] - g[f"{name}_val"]).max() <= 10 * TOL * rms, name
+        assert abs(np.abs(a).sum() - sa) <= TOL * sa, name
+        assert abs((a * a).sum() - sq) <= 2 * TOL * sq, name
+
+
+@pytest.mark.parametrize("n,f,t", [(3, 20, 36), (1, 48, 100), (2, 31, 16), (1, 16, 130)])
+def test_unet_matches_oracle_all_blocks(net, dev, weights_np, n, f, t):
+    """Seeded shapes not among the goldens (odd sizes, width-only / height-only pads), every block output."""
+    import oracle
+    from audiodenoiser_amd.weights import make_input
+    x = make_input(21, n, f, t)
+    ref, rtaps = oracle.unet_forward(weights_np, x, acc64=True, want_taps=True)
+    with torch.no_grad():
+        y, taps = net(torch.from_numpy(x).to(dev), return_taps=True)
+    for name in oracle.TAP_NAMES:
+        a = taps[name].cpu().numpy()
+        assert a.shape == rtaps[name].shape, name
+        assert _rel(a, rtaps[name]) <= TOL, name
+    assert _rel(y.cpu().numpy(), ref) <= TOL
+
+
+def test_unet_full_size_batch64(net, dev, weights_np):
+    """BASELINE config 2 (batch 64 x 513 x 256): size-independent properties + two clips against the oracle."""
+    from oracle import unet_torch
+    from audiodenoiser_amd.weights import make_input
+    n, f, t = 64, 513, 256
+    x = torch.from_numpy(make_input(0, n, f, t, scale=4.0)).to(dev)
+    with torch.no_grad():
+        y = net(x)
+        # (1) clip independence: a clip computed alone is bit-identical to the same clip inside the batch
+        for i in (0, 37, 63):
+            yi = net(x[i:i + 1].clone())
+            assert torch.equal(yi[0], y[i]), i
+        # (2) batch order equivariance, bit exact
+        perm = torch.randperm(n, generator=torch.Generator().manual_seed(1)).to(dev)
+        assert torch.equal(net(x[perm].contiguous()), y[perm])
+    assert torch.isfinite(y).all()
+    # (3) oracle (same ATen/oneDNN kernels as the reference) on two clips
+    sd = unet_torch.to_torch_state(weights_np)
+    for i in (5, 63):
+        ref = unet_torch.unet_forward(sd, x[i:i + 1].cpu()).numpy()
+        assert _rel(y[i:i + 1].cpu().numpy(), ref) <= TOL
+
+
+def test_unet_weights_follow_state_dict_updates(dev, weights_np):
+    """load_state_dict / in-place edits re-pack the weights (BatchNorm fold is redone)."""
+    import oracle
+    from audiodenoiser_amd.model import UNet
+    from audiodenoiser_amd.weights import make_input, make_state_dict
+    m = UNet().to(dev).eval()
+    x = make_input(3, 1, 16, 16)
+    sd2 = make_state_dict(99)
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in weights_np.items()})
+    with torch.no_grad():
+        y1 = m(torch.from_numpy(x).to(dev)).cpu().numpy()
+        m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd2.items()})
+        y2 = m(torch.from_numpy(x).to(dev)).cpu().numpy()
+        assert _rel(y1, oracle.unet_forward(weights_np, x, acc64=True)) <= TOL
+        assert _rel(y2, oracle.unet_forward(sd2, x, acc64=True)) <= TOL
+        m.out.bias.add_(1.0)
+        y3 = m(torch.from_numpy(x).to(dev)).cpu().numpy()
+    assert np.allclose(y3, y2 + 1.0, atol=1e-5)
+
+
+def test_c_abi_error_paths(net, dev):
+    from audiodenoiser_amd import _lib
+    L = _lib.load()
+    x = torch.zeros(1, 1, 16, 16, device=dev)
+    with torch.no_grad():
+        net(x)                                          # make sure a handle exists
+    h = net._handle
+    y = torch.empty_like(x)
+    ws = torch.empty(16, dtype=torch.uint8, device=dev)
+    rc = L.adn_unet_forward(h, x.data_ptr(), y.data_ptr(), 1, 16, 16, ws.data_ptr(), ws.numel(), None)
+    assert rc == 3 and b"workspace" in L.adn_last_error()
+    rc = L.adn_unet_forward(h, x.data_ptr(), y.data_ptr(), 1, 8, 16, ws.data_ptr(), ws.numel(), None)
+    assert rc == 1
+    with torch.no_grad(), pytest.raises(ValueError):
+        net(torch.zeros(1, 1, 15, 64, device=dev))
+    with torch.no_grad(), pytest.raises(ValueError):
+        net(torch.zeros(1, 2, 16, 16, device=dev))
+
+
+# ---------------------------------------------------------------------------------------------- STFT
+STFT_CASES = [(16000, 512, 128, False), (24000, 512, 128, True), (132300, 1024, 256, True),
+              (132300, 1024, 256, False), (5000, 2048, 512, True), (4096, 4096, 1024, False),
+              (700, 64, 16, True), (1000, 128, 100, True), (3000, 256, 64, False), (1024, 1024, 256, False)]
+
+
+@pytest.mark.parametrize("L,n_fft,hop,center", STFT_CASES)
+def test_stft_matches_oracle(dev, L, n_fft, hop, center):
+    import oracle
+    from audiodenoiser_amd.stft import stft_magnitude
+    from audiodenoiser_amd.weights import make_audio
+    a = make_audio(3, 3, L)
+    ref = oracle.stft_mag(a, n_fft, hop, center)
+    got = stft_magnitude(torch.from_numpy(a).to(dev), n_fft, hop, center).cpu().numpy()
+    assert got.shape == ref.shape
+    assert _rel(got, ref) <= TOL
+
+
+def test_stft_reference_helpers_numpy_in_numpy_out(dev):
+    import oracle
+    from audiodenoiser_amd.stft import audio_to_magnitude_spectrogram, audio_to_spectrogram
+    from audiodenoiser_amd.weights import make_audio
+    chunk = make_audio(5, 1, 16000)[0]       # 2 s @ 8 kHz train chunk (create_train_dataset.py:22-23)
+    m = audio_to_magnitude_spectrogram(chunk)
+    assert isinstance(m, np.ndarray) and m.dtype == np.float32 and m.shape == (257, 122)
+    assert _rel(m, oracle.stft_mag(chunk, 512, 128, False)) <= TOL
+    clip = make_audio(6, 1, 24000)[0]        # 3 s test clip (create_test_dataset.py:39)
+    m = audio_to_spectrogram(clip)
+    assert m.shape == (257, 188)
+    assert _rel(m, oracle.stft_mag(clip, 512, 128, True)) <= TOL
+
+
+def test_stft_known_answers(dev):
+    from audiodenoiser_amd.stft import stft_magnitude
+    n, hop = 1024, 256
+    L = n * 4
+    i = np.arange(L)
+    k0, amp = 100, 0.7
+    x = (amp * np.cos(2 * np.pi * k0 * i / n)).astype(np.float32)
+    m = stft_magnitude(torch.from_numpy(x).to(dev), n, hop, False).cpu().numpy()
+    assert np.allclose(m[k0], amp * n / 4, rtol=1e-4) and np.allclose(m[k0 - 1], amp * n / 8, rtol=1e-4)
+    rest = np.delete(m, [k0 - 1, k0, k0 + 1], axis=0)
+    assert rest.max() < 1e-3 * amp * n / 4
+    imp = np.zeros(L, np.float32)
+    imp[300] = 1.0
+    m = stft_magnitude(torch.from_numpy(imp).to(dev), n, hop, False).cpu().numpy()
+    assert np.allclose(m[:, 0], 0.5 - 0.5 * np.cos(2 * np.pi * 300 / n), atol=1e-6)
+    assert np.allclose(m[:, 1], 0.5 - 0.5 * np.cos(2 * np.pi * 44 / n), atol=1e-6)   # sample 300 is index 44 of frame 1
+
+
+def test_stft_full_size_properties(dev):
+    """BASELINE config 3 shape (132300-sample clips, 1024/256, centred) at 2000 clips: exact homogeneity,
+    clip independence, and three clips against the oracle."""
+    import oracle
+    from audiodenoiser_amd.stft import stft_magnitude
+    n_clips, L = 2000, 132300
+    g = torch.Generator(device=dev).manual_seed(0)
+    a = torch.rand((n_clips, L), generator=g, device=dev) * 2 - 1
+    m = stft_magnitude(a, 1024, 256, True)
+    assert m.shape == (n_clips, 513, 517) and torch.isfinite(m).all()
+    assert torch.equal(stft_magnitude(a * 2.0, 1024, 256, True), m * 2.0)          # scaling by 2 is exact
+    for i in (0, 777, n_clips - 1):
+        assert torch.equal(stft_magnitude(a[i], 1024, 256, True), m[i])
+        assert _rel(m[i].cpu().numpy(), oracle.stft_mag(a[i].cpu().numpy(), 1024, 256, True)) <= TOL
+
+
+def test_stft_rejects_bad_arguments(dev):
+    from audiodenoiser_amd._lib import AdnError
+    from audiodenoiser_amd.stft import stft_magnitude
+    a = torch.zeros(1000, device=dev)
+    with pytest.raises(ValueError):
+        stft_magnitude(a, 2048, 512, False)
+    with pytest.raises(AdnError):
+        stft_magnitude(a, 500, 128, True)
+    with pytest.raises(RuntimeError):
+        stft_magnitude(torch.zeros(1000), 512, 128, True)
+
+
+# ---------------------------------------------------------------------------------------------- loader / loss
+def test_quantize_pad_bit_exact(dev, golden_dir):
+    from audiodenoiser_amd.data_loader import quantize_pad_on_device
+    from audiodenoiser_amd.weights import hash_uniform
+    g = np.load(os.path.join(golden_dir, "loader_cases.npz"))
+    for ci in range(4):
+        shape = tuple(g[f"case{ci}_in_shape"])
+        target = tuple(g[f"case{ci}_target"])
+        u = hash_uniform(5, f"loader{ci}", 2 * shape[0] * shape[1]).reshape(2, *shape)
+        noisy = (u[0] * np.float32(8.0)).astype(np.float32)
+        clean = (u[1] * np.float32(8.0)).astype(np.float32)
+        noisy[0, 0], noisy[0, 1], noisy[0, 2], noisy[1, 0] = 70000.0, 1e-8, 3e-6, 65504.0
+        out = quantize_pad_on_device(torch.from_numpy(np.stack([noisy, clean])).to(dev), target).cpu().numpy()
+        assert out.shape == (2, 1) + target
+        assert np.array_equal(out[0], g[f"case{ci}_noisy"]) and np.array_equal(out[1], g[f"case{ci}_clean"])
+
+
+def test_quantize_pad_random_bit_patterns(dev):
+    from audiodenoiser_amd.data_loader import quantize_pad_on_device
+    bits = np.random.default_rng(0).integers(0, 2 ** 32, size=(1, 512, 512), dtype=np.uint64).astype(np.uint32)
+    x = bits.view(np.float32)
+    x = np.where(np.isnan(x), np.float32(1.0), x)
+    with np.errstate(over="ignore"):
+        ref = x.astype(np.float16).astype(np.float32)
+    out = quantize_pad_on_device(torch.from_numpy(x).to(dev), (512, 512)).cpu().numpy()
+    assert np.array_equal(out[:, 0], ref)
+
+
+def test_per_clip_l1(dev):
+    from audiodenoiser_amd.loss import per_clip_l1
+    g = torch.Generator().manual_seed(0)
+    a = torch.rand((5, 1, 33, 47), generator=g)
+    b = torch.rand((5, 1, 33, 47), generator=g)
+    got = per_clip_l1(a.to(dev), b.to(dev)).cpu().numpy()
+    ref = (a.double() - b.double()).abs().reshape(5, -1).mean(dim=1).numpy()
+    assert np.allclose(got, ref, rtol=1e-5)
