@@ -27,6 +27,11 @@ def load() -> ctypes.CDLL:
             path = _build.build()
         except Exception as exc:  # noqa: BLE001 - re-raised with context
             raise AdnError(f"libadn.so (MI355X HIP kernels) is missing and could not be built: {exc}") from exc
+        # PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so, soname libamdhip64.so.7).  It must be
+        # in the process BEFORE libadn.so is mapped so that libadn's NEEDED libamdhip64.so.7 binds to that same
+        # runtime instance (streams and allocations are shared with torch); loading libadn first would pull in
+        # /opt/rocm's copy and leave two HIP runtimes in one process.
+        import torch  # noqa: F401
         try:
             L = ctypes.CDLL(path)
         except OSError as exc:
