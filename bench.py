@@ -38,31 +38,58 @@ import torch  # noqa: E402
 F_BINS, T_FRAMES = 513, 256
 
 
+def host_cores() -> int:
+    """CPU share of this process: min(affinity, cgroup quota); shared GPU boxes expose every core in the
+    affinity mask but throttle by quota, and oversubscribing oneDNN threads collapses its throughput."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(sd_np, budget_s: float = 12.0):
-    """Reference-equivalent CPU forward (oracle/unet_torch.py) on B=2 batches of 513x256, all host cores."""
+    """Reference-equivalent CPU forward (oracle/unet_torch.py) on 513x256 clips, on this host's cores.
+
+    The thread count is chosen by a short probe (one clip each at the candidate counts) so that the CPU is
+    shown at its best; `cores` reports the threads actually used for the timed sample."""
     from oracle import unet_torch
     from audiodenoiser_amd.weights import make_input
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        pass
-    torch.set_num_threads(cores)
+    share = host_cores()
     sd = unet_torch.to_torch_state(sd_np)
     b = 2
     x = torch.from_numpy(make_input(0, b, F_BINS, T_FRAMES, scale=4.0))
-    unet_torch.unet_forward(sd, x[:1])          # warm-up (oneDNN primitive creation)
+    best_n, best_t = None, None
+    for n in sorted({min(share, c) for c in (8, 16, 32, 64, share)}):
+        torch.set_num_threads(n)
+        unet_torch.unet_forward(sd, x[:1])      # warm-up at this thread count (oneDNN primitive creation)
+        t0 = time.perf_counter()
+        unet_torch.unet_forward(sd, x[:1])
+        dt = time.perf_counter() - t0
+        if best_t is None or dt < best_t:
+            best_n, best_t = n, dt
+        if dt > 6.0:
+            break
+    torch.set_num_threads(best_n)
     t0 = time.perf_counter()
     iters = 0
     while True:
         unet_torch.unet_forward(sd, x)
         iters += 1
         el = time.perf_counter() - t0
-        if el >= budget_s or iters >= 8:
+        if el >= budget_s or iters >= 16:
             break
-    return {"value": round(iters * b * T_FRAMES / el, 1), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{iters} forwards of batch {b} x 513x256 fp32 ({el:.1f} s), oracle/unet_torch.py "
-                      f"(torch {torch.__version__} CPU, oneDNN), after 1 warm-up"}
+    return {"value": round(iters * b * T_FRAMES / el, 1), "unit": "frames/s", "cores": best_n, "kind": "port",
+            "sample": f"{iters} forwards of batch {b} x 513x256 fp32 ({el:.1f} s) with {best_n} threads "
+                      f"(host share {share}), oracle/unet_torch.py = torch {torch.__version__} CPU/oneDNN, "
+                      "the kernels the reference's model.py dispatches to"}
 
 
 def main() -> None:
