@@ -482,6 +482,8 @@ int adn_stft_mag(const float *audio, int n_clips, long length, int n_fft, int ho
     if (n_clips < 1 || hop < 1) return fail(ADN_ERR_INVALID, "adn_stft_mag: n_clips and hop must be >= 1");
     if (n_fft < 64 || n_fft > 4096 || (n_fft & (n_fft - 1)))
         return fail(ADN_ERR_INVALID, "adn_stft_mag: n_fft must be a power of two in [64, 4096]");
+    if (length >= (1L << 30) || hop > (1 << 20))
+        return fail(ADN_ERR_INVALID, "adn_stft_mag: clip length must be < 2^30 samples and hop <= 2^20");
     long nfr = 0;
     adn_stft_n_frames(length, n_fft, hop, center, &nfr);
     if (nfr <= 0) return fail(ADN_ERR_INVALID, "adn_stft_mag: audio shorter than n_fft");

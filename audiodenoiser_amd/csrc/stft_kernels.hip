@@ -17,6 +17,7 @@
 #include "adn_internal.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -226,6 +227,279 @@ __global__ __launch_bounds__(STFT_THREADS) void stft_mag_kernel(const float *__r
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wave-synchronous variant for n_fft <= 1024 (a frame fits one wave: M/8 <= 64 threads).
+//
+// No workgroup barrier inside the FFT: a frame's 8-point-per-thread exchanges go through a private LDS
+// slot and rely on the in-order execution of one wave's DS instructions, so waves drift freely and hide
+// each other's global/LDS latency.  All per-thread constants (window, twiddles of every pass, the real-FFT
+// post-twiddles) live in registers, loaded once per workgroup.  Frames are read straight from global memory
+// (8-byte coalesced loads; the 75 % overlap between consecutive frames is served by L1/L2), the exchange image
+// is padded by one element per 8 (conflict-free ds_write_b64 / ds_read_b64), and magnitudes are transposed
+// through an LDS [bin][frame] image so that HBM stores run along the frame axis.
+// ------------------------------------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2f vmul(v2f a, v2f b)   // complex multiply, packed-math friendly
+{
+    const v2f bs = {-b.y, b.x};
+    return a.x * b + a.y * bs;
+}
+__device__ __forceinline__ v2f vnegi(v2f a) { return v2f{a.y, -a.x}; }
+
+template <int R>
+__device__ __forceinline__ void vdft(v2f *v);
+template <>
+__device__ __forceinline__ void vdft<2>(v2f *v)
+{
+    const v2f a = v[0], b = v[1];
+    v[0] = a + b;
+    v[1] = a - b;
+}
+template <>
+__device__ __forceinline__ void vdft<4>(v2f *v)
+{
+    const v2f t0 = v[0] + v[2], t1 = v[0] - v[2], t2 = v[1] + v[3], t3 = vnegi(v[1] - v[3]);
+    v[0] = t0 + t2;
+    v[1] = t1 + t3;
+    v[2] = t0 - t2;
+    v[3] = t1 - t3;
+}
+template <>
+__device__ __forceinline__ void vdft<8>(v2f *v)
+{
+    v2f e[4] = {v[0], v[2], v[4], v[6]};
+    v2f o[4] = {v[1], v[3], v[5], v[7]};
+    vdft<4>(e);
+    vdft<4>(o);
+    const float s = 0.70710678118654752440f;
+    o[1] = v2f{s * (o[1].x + o[1].y), s * (o[1].y - o[1].x)};
+    o[2] = vnegi(o[2]);
+    o[3] = v2f{s * (o[3].y - o[3].x), -s * (o[3].x + o[3].y)};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        v[q] = e[q] + o[q];
+        v[q + 4] = e[q] - o[q];
+    }
+}
+
+__device__ __forceinline__ int phys(int j) { return j + (j >> 3); }   // exchange image: 1 pad element per 8
+
+__device__ __forceinline__ void wave_lds_fence()
+{
+    // order this wave's LDS accesses for the compiler; the hardware runs one wave's DS ops in order
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// One Stockham pass (radix R, P = product of earlier radices) with the twiddles in registers `tw`
+// ((R-1) per butterfly, butterfly-major).
+template <int M, int R, int P>
+__device__ __forceinline__ void wave_pass(v2f *sc, const v2f *tw, int t, v2f *v)
+{
+    constexpr int TPF = M / 8, NBF = 8 / R, T = M / R;
+#pragma unroll
+    for (int b = 0; b < NBF; ++b)
+#pragma unroll
+        for (int u = 0; u < R; ++u) v[b * R + u] = sc[phys(t + b * TPF + u * T)];
+    wave_lds_fence();
+#pragma unroll
+    for (int b = 0; b < NBF; ++b) {
+        const int i = t + b * TPF;
+        const int k = i & (P - 1);
+#pragma unroll
+        for (int u = 1; u < R; ++u) v[b * R + u] = vmul(v[b * R + u], tw[b * (R - 1) + u - 1]);
+        vdft<R>(v + b * R);
+        const int j = (i - k) * R + k;
+#pragma unroll
+        for (int q = 0; q < R; ++q) sc[phys(j + q * P)] = v[b * R + q];
+    }
+    wave_lds_fence();
+}
+
+template <int M, int R, int P>
+__device__ __forceinline__ void load_pass_twiddles(const float *tables, int t, v2f *tw)
+{
+    constexpr int TPF = M / 8, NBF = 8 / R, N = 2 * M;
+    const v2f *gtw = reinterpret_cast<const v2f *>(tables + N);
+#pragma unroll
+    for (int b = 0; b < NBF; ++b) {
+        const int k = (t + b * TPF) & (P - 1);
+#pragma unroll
+        for (int u = 1; u < R; ++u) tw[b * (R - 1) + u - 1] = gtw[(u * k * (M / (P * R))) & (M - 1)];
+    }
+}
+
+// radix plan: pass 1 is always radix 8 (P=1, no twiddles); then (R2,P2=8) and (R3,P3=8*R2) where present
+template <int M> struct WavePlan;
+template <> struct WavePlan<32>  { static constexpr int R2 = 4, R3 = 1; };
+template <> struct WavePlan<64>  { static constexpr int R2 = 8, R3 = 1; };
+template <> struct WavePlan<128> { static constexpr int R2 = 8, R3 = 2; };
+template <> struct WavePlan<256> { static constexpr int R2 = 8, R3 = 4; };
+template <> struct WavePlan<512> { static constexpr int R2 = 8, R3 = 8; };
+
+// Bijective remap of the workgroup id so that workgroups placed on one XCD (ids congruent mod 8 under the
+// observed round-robin placement) own neighbouring frame groups: the two halves of an output cache line and the
+// overlapping audio lines then meet in ONE L2 instead of being written back / fetched partially by several.
+// Affects speed only.
+__device__ __forceinline__ int stft_xcd_remap(int b, int nwg)
+{
+    const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
+
+template <int M, int NW, int FPB>
+__global__ __launch_bounds__(NW * 64) void stft_wave_kernel(const float *__restrict__ audio, long L, int hop, int pad,
+                                                             long n_frames, int groups_per_clip, int gpb,
+                                                             int blocks_per_clip, const float *__restrict__ tables,
+                                                             float *__restrict__ out, int ablate)
+{
+    constexpr int N = 2 * M, TPF = M / 8, NT = NW * 64;
+    constexpr int SLOTS = NT / TPF, FPS = FPB / SLOTS;      // frames per slot and group, processed in sequence
+    constexpr int MAGSTR = FPB + 1;
+    constexpr int SCSZ = M + M / 8;                          // padded exchange image (v2f elements)
+    constexpr int R2 = WavePlan<M>::R2, R3 = WavePlan<M>::R3;
+    static_assert(TPF <= 64 && FPB % SLOTS == 0 && FPS >= 1 && NT % FPB == 0, "bad STFT tiling");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *s_mag = smem;                                                   // (M+1) * MAGSTR
+    v2f *s_sc = reinterpret_cast<v2f *>(smem + (((M + 1) * MAGSTR + 1) & ~1));
+
+    const int tid = threadIdx.x;
+    const int slot = tid / TPF, t = tid - slot * TPF;
+    const int lid = stft_xcd_remap(blockIdx.x, gridDim.x);
+    const int clip = lid / blocks_per_clip;
+    const int g_first = (lid - clip * blocks_per_clip) * gpb;
+    const int g_end = min(g_first + gpb, groups_per_clip);
+    const float *aud = audio + (long)clip * L;
+    float *oclip = out + (long)clip * (M + 1) * n_frames;
+    v2f *sc = s_sc + slot * SCSZ;
+
+    // ---- per-thread constants, loaded once per workgroup and kept in registers over all its frames ----
+    v2f win[8], tw2[(R2 - 1) * (8 / R2)], tw3[R3 > 1 ? (R3 - 1) * (8 / R3) : 1], twp[4];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) win[u] = *reinterpret_cast<const v2f *>(tables + 2 * (t + u * TPF));
+    load_pass_twiddles<M, R2, 8>(tables, t, tw2);
+    if constexpr (R3 > 1) load_pass_twiddles<M, R3, 8 * R2>(tables, t, tw3);
+    {
+        const v2f *g2 = reinterpret_cast<const v2f *>(tables + N + 2 * M);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) twp[b] = g2[t + b * TPF];
+    }
+
+    const int Li = (int)L;                                // adn_stft_mag guarantees L < 2^30
+    const bool base_aligned = (reinterpret_cast<uintptr_t>(aud) & 7) == 0;
+
+    // raw (unwindowed) samples of frame `fidx` of this clip -> dst[8]
+    auto load_frame = [&](int fidx, v2f *dst) {
+        const int fstart = fidx * hop - pad;               // may be < 0 (centre padding) or run past the clip
+        const float *ap = aud + fstart + 2 * t;
+        if (ablate & 1) {                                  // timing experiment only: no audio traffic
+#pragma unroll
+            for (int u = 0; u < 8; ++u) dst[u] = v2f{(float)(fidx + u), 1.f};
+        } else if (fstart >= 0 && fstart + N <= Li && base_aligned && !(fstart & 1)) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) dst[u] = *reinterpret_cast<const v2f *>(ap + 2 * u * TPF);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int s = fstart + 2 * (t + u * TPF);
+                dst[u].x = (s >= 0 && s < Li) ? ap[2 * u * TPF] : 0.f;
+                dst[u].y = (s + 1 >= 0 && s + 1 < Li) ? ap[2 * u * TPF + 1] : 0.f;
+            }
+        }
+    };
+
+    // this slot's frame sequence: groups g_first..g_end-1, FPS consecutive frames in each
+    const int n_seq = (g_end - g_first) * FPS;
+    v2f nx[8];
+    load_frame(g_first * FPB + slot * FPS, nx);
+    int g = g_first, fi = 0;
+#pragma unroll 1
+    for (int it = 0; it < n_seq; ++it) {
+        const int fcol = slot * FPS + fi;
+        v2f v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = nx[u] * win[u];
+        // software prefetch: the next frame's loads fly under this frame's FFT
+        int gn = g, fn = fi + 1;
+        if (fn == FPS) { fn = 0; ++gn; }
+        if (it + 1 < n_seq) load_frame(gn * FPB + slot * FPS + fn, nx);
+
+        // pass 1: radix 8, P = 1
+        vdft<8>(v);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sc[9 * t + q] = v[q];          // phys(8t + q) = 9t + q
+        wave_lds_fence();
+        wave_pass<M, R2, 8>(sc, tw2, t, v);
+        if constexpr (R3 > 1) wave_pass<M, R3, 8 * R2>(sc, tw3, t, v);
+
+        // ---- real-FFT post-processing + magnitude into the [bin][frame] image ----
+        float *mg = s_mag + fcol;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int k = t + b * TPF;
+            const v2f A = sc[phys(k)], Bc = sc[phys((M - k) & (M - 1))];   // k = 0 pairs with itself
+            const v2f Bz = {Bc.x, -Bc.y};
+            const v2f ev = 0.5f * (A + Bz), d = 0.5f * (A - Bz);
+            const v2f wo = vmul(twp[b], vnegi(d));
+            const v2f xa = ev + wo, xb = ev - wo;
+            // k = 0: ev = (Re z0, 0), wo = (Im z0, 0)  ->  |xa| = |X[0]|, |xb| = |X[M]|  (same formulas)
+            mg[k * MAGSTR] = __builtin_amdgcn_sqrtf(xa.x * xa.x + xa.y * xa.y);
+            mg[(M - k) * MAGSTR] = __builtin_amdgcn_sqrtf(xb.x * xb.x + xb.y * xb.y);
+        }
+        if (t == 0) {
+            const v2f zh = sc[phys(M / 2)];
+            mg[(M / 2) * MAGSTR] = __builtin_amdgcn_sqrtf(zh.x * zh.x + zh.y * zh.y);
+        }
+        wave_lds_fence();     // the slot's exchange image is reused by its next frame
+
+        if (fi == FPS - 1) {
+            // ---- group complete: store with lanes along the frame axis; thread = (frame column, bin row) ----
+            __syncthreads();
+            constexpr int ROWS = NT / FPB;
+            const int fr = tid % FPB, k0 = tid / FPB;
+            const long fglob = (long)g * FPB + fr;
+            if (fglob < n_frames && !((ablate & 2) && k0 > 0)) {   // ablate&2: timing experiment, one row only
+                float *op = oclip + (long)k0 * n_frames + fglob;
+                const float *mp = s_mag + k0 * MAGSTR + fr;
+                const long ostep = (long)ROWS * n_frames;
+#pragma unroll 4
+                for (int k = k0; k < ((ablate & 2) ? 1 : M + 1); k += ROWS) {
+                    *op = *mp;
+                    op += ostep;
+                    mp += ROWS * MAGSTR;
+                }
+            }
+            __syncthreads();   // image is rewritten by the next group
+        }
+        fi = fn;
+        g = gn;
+    }
+}
+
+template <int M, int NW, int FPB>
+hipError_t launch_wave(const float *audio, int n_clips, long L, int hop, int pad, long n_frames, const float *tables,
+                       float *out, hipStream_t st, int gpb)
+{
+    constexpr int TPF = M / 8, SLOTS = NW * 64 / TPF;
+    const long groups = (n_frames + FPB - 1) / FPB;
+    if (gpb < 1) gpb = 1;
+    if (gpb > groups) gpb = (int)groups;
+    const long bpc = (groups + gpb - 1) / gpb;
+    const long nwg = bpc * n_clips;
+    if (nwg <= 0 || nwg > 0x7fffffffL) return hipErrorInvalidValue;
+    const size_t lds = (size_t)((((M + 1) * (FPB + 1) + 1) & ~1) + 2 * SLOTS * (M + M / 8)) * sizeof(float);
+    auto kern = stft_wave_kernel<M, NW, FPB>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(NW * 64), lds, st, audio, L, hop, pad, n_frames, (int)groups,
+                       gpb, (int)bpc, tables, out, []() { const char *a = std::getenv("ADN_STFT_ABLATE"); return a ? std::atoi(a) : 0; }());
+    return hipGetLastError();
+}
+
 struct TableKey {
     int device, n_fft;
     bool operator<(const TableKey &o) const { return device != o.device ? device < o.device : n_fft < o.n_fft; }
@@ -297,6 +571,25 @@ hipError_t launch_stft_mag(const float *audio, int n_clips, long L, int n_fft, i
     hipError_t e = get_tables(n_fft, &tables);
     if (e != hipSuccess) return e;
     const int pad = center ? n_fft / 2 : 0;
+    // experiment switch (tools/bench_stft.py A/B runs); 0 = workgroup-synchronous kernel, unset = default
+    const char *ev = std::getenv("ADN_STFT_VARIANT");
+    const int variant = ev ? std::atoi(ev) : -1;
+    const char *eg = std::getenv("ADN_STFT_GPB");
+    const int gpb = eg ? std::atoi(eg) : 1;               // frame groups per workgroup (1 measured best: no in-loop barriers)
+    if (variant != 0) {
+        switch (n_fft) {
+            case 64: return launch_wave<32, 1, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
+            case 128: return launch_wave<64, 2, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
+            case 256: return launch_wave<128, 4, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
+            case 512: return launch_wave<256, 8, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
+            case 1024:
+                if (variant == 1) return launch_wave<512, 8, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
+                if (variant == 3) return launch_wave<512, 8, 32>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
+                if (variant == 4) return launch_wave<512, 4, 32>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
+                return launch_wave<512, 4, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
+            default: break;
+        }
+    }
     switch (n_fft) {
         case 64: return launch_m<32>(audio, n_clips, L, hop, pad, n_frames, tables, out, st);
         case 128: return launch_m<64>(audio, n_clips, L, hop, pad, n_frames, tables, out, st);
