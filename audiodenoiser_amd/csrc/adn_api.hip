@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -55,6 +56,8 @@ struct adn_unet {
     // optional per-launch timing (adn_unet_set_timing)
     std::vector<hipEvent_t> events;
     int timing_max = 0, timing_count = 0;
+    bool use_wino = true;          // 3x3 layers: Winograd F(2x2,3x3) kernel (false: direct implicit GEMM)
+    int wino_bn = 32;              // couts per Winograd workgroup (32: two 4-wave workgroups per CU; 64: one 8-wave)
 };
 
 namespace {
@@ -93,6 +96,30 @@ void pack_conv3x3(const float *w /*(Cout,Cin,3,3)*/, const std::vector<float> &s
                                 dst[o++] = w[((size_t)co * Cin + ci) * 9 + tap] * scale[co];
                             }
                         }
+}
+
+// Winograd F(2x2,3x3) weights U = G g G^T (double precision, BatchNorm scale folded), packed for wino_conv_f32:
+// [column tile of 64][chunk of 8 channels][pos = 4*xi+nu][q][n][e] with input channel = chunk*8 + 2q + e.
+void pack_wino3x3(const float *w /*(Cout,Cin,3,3)*/, const std::vector<float> &scale, int Cin, int Cout, int BN,
+                  float *dst)
+{
+    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    const int nct = Cout / BN, nchunk = Cin / 8;
+    for (int co = 0; co < Cout; ++co)
+        for (int ci = 0; ci < Cin; ++ci) {
+            const float *g = w + ((size_t)co * Cin + ci) * 9;
+            double tmp[4][3], U[4][4];
+            for (int x = 0; x < 4; ++x)
+                for (int b = 0; b < 3; ++b)
+                    tmp[x][b] = G[x][0] * g[0 * 3 + b] + G[x][1] * g[1 * 3 + b] + G[x][2] * g[2 * 3 + b];
+            for (int x = 0; x < 4; ++x)
+                for (int v = 0; v < 4; ++v)
+                    U[x][v] = (tmp[x][0] * G[v][0] + tmp[x][1] * G[v][1] + tmp[x][2] * G[v][2]) * (double)scale[co];
+            const int ct = co / BN, n = co % BN, ch = ci / 8, q = (ci % 8) / 2, e = ci & 1;
+            float *blk = dst + ((size_t)ct * nchunk + ch) * (16 * 4 * BN * 2);
+            for (int pos = 0; pos < 16; ++pos) blk[((pos * 4 + q) * BN + n) * 2 + e] = (float)U[pos >> 2][pos & 3];
+        }
+    (void)nct;
 }
 
 // ConvTranspose2d(k2,s2) as a GEMM with columns col = (i*2+j)*Cout + co, K = Cin.
@@ -151,7 +178,8 @@ bool make_plan(int N, int F, int T, Plan &p)
 adn::ConvArgs conv_args(const adn_unet *h, const Conv3x3Layer &L, adn::ConvKind kind, const float *in0, int C0,
                         const float *in1, int C1, int H1, int W1, float *out, float *pool, int N, int H, int W)
 {
-    const adn::ConvGeom g = adn::conv_geom(kind, L.Cout);
+    adn::ConvGeom g = adn::conv_geom(kind, L.Cout);
+    if (h->use_wino) g = adn::ConvGeom{16, h->wino_bn, 8};   // wino_conv_f32 tile: 16x16 px x wino_bn couts, 8-ch chunks
     adn::ConvArgs a;
     a.s0 = adn::ConvSrc{in0, H, W, C0, 0, 0};
     if (in1) {
@@ -173,7 +201,13 @@ adn::ConvArgs conv_args(const adn_unet *h, const Conv3x3Layer &L, adn::ConvKind 
     a.tilesY = (H + g.TH - 1) / g.TH;
     a.tilesX = (W + 15) / 16;
     a.nct = L.Cout / g.BN;
+    a.ablate = 0;
     return a;
+}
+
+hipError_t launch_conv3(const adn_unet *h, adn::ConvKind kind, const adn::ConvArgs &a, hipStream_t st)
+{
+    return h->use_wino ? adn::launch_wino_conv(kind, a, h->wino_bn, st) : adn::launch_conv_mfma(kind, a, st);
 }
 
 int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, void *workspace, size_t ws_bytes,
@@ -215,14 +249,14 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
             adn::ConvArgs a = conv_args(h, h->c3[li], adn::CONV3X3_RELU, ws + p.pool[l - 1], CH[l - 1], nullptr, 0, 0, 0,
                                         tA, nullptr, N, p.H[l], p.W[l]);
             ADN_MARK();
-            ADN_HIP(adn::launch_conv_mfma(adn::CONV3X3_RELU, a, st));
+            ADN_HIP(launch_conv3(h, adn::CONV3X3_RELU, a, st));
             ++li;
             cur = tA;
         }
         adn::ConvArgs a = conv_args(h, h->c3[li], adn::CONV3X3_RELU_POOL, cur, CH[l], nullptr, 0, 0, 0, skip, pool, N,
                                     p.H[l], p.W[l]);
         ADN_MARK();
-        ADN_HIP(adn::launch_conv_mfma(adn::CONV3X3_RELU_POOL, a, st));
+        ADN_HIP(launch_conv3(h, adn::CONV3X3_RELU_POOL, a, st));
         ++li;
         ADN_HIP(export_tap(l, skip, CH[l], p.H[l], p.W[l]));
     }
@@ -231,12 +265,12 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
         adn::ConvArgs a = conv_args(h, h->c3[li], adn::CONV3X3_RELU, ws + p.pool[3], 512, nullptr, 0, 0, 0, tA, nullptr, N,
                                     p.H[4], p.W[4]);
         ADN_MARK();
-        ADN_HIP(adn::launch_conv_mfma(adn::CONV3X3_RELU, a, st));
+        ADN_HIP(launch_conv3(h, adn::CONV3X3_RELU, a, st));
         ++li;
         adn::ConvArgs b = conv_args(h, h->c3[li], adn::CONV3X3_RELU, tA, 1024, nullptr, 0, 0, 0, tB, nullptr, N, p.H[4],
                                     p.W[4]);
         ADN_MARK();
-        ADN_HIP(adn::launch_conv_mfma(adn::CONV3X3_RELU, b, st));
+        ADN_HIP(launch_conv3(h, adn::CONV3X3_RELU, b, st));
         ++li;
         ADN_HIP(export_tap(4, tB, 1024, p.H[4], p.W[4]));
     }
@@ -262,17 +296,18 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
         t.tilesY = (uh + g.TH - 1) / g.TH;
         t.tilesX = (uw + 15) / 16;
         t.nct = 4 * co / g.BN;
+        t.ablate = 0;
         ADN_MARK();
         ADN_HIP(adn::launch_conv_mfma(adn::CONVT2X2, t, st));
         // first conv of the DoubleConv reads cat([skip, x1]) virtually
         adn::ConvArgs a = conv_args(h, h->c3[li], adn::CONV3X3_RELU, ws + p.skip[l], co, Y, co, 2 * uh, 2 * uw, X, nullptr,
                                     N, p.H[l], p.W[l]);
         ADN_MARK();
-        ADN_HIP(adn::launch_conv_mfma(adn::CONV3X3_RELU, a, st));
+        ADN_HIP(launch_conv3(h, adn::CONV3X3_RELU, a, st));
         ++li;
         adn::ConvArgs b = conv_args(h, h->c3[li], adn::CONV3X3_RELU, X, co, nullptr, 0, 0, 0, Y, nullptr, N, p.H[l], p.W[l]);
         ADN_MARK();
-        ADN_HIP(adn::launch_conv_mfma(adn::CONV3X3_RELU, b, st));
+        ADN_HIP(launch_conv3(h, adn::CONV3X3_RELU, b, st));
         ++li;
         ADN_HIP(export_tap(5 + (3 - l), Y, co, p.H[l], p.W[l]));
         float *tmp = X;
@@ -334,6 +369,10 @@ int adn_unet_create(adn_unet **handle, int device, const float *const *t, int n_
 
     adn_unet *h = new adn_unet();
     h->device = device;
+    if (const char *algo = std::getenv("ADN_CONV_ALGO")) {      // experiment switch: direct | wino32 | wino64
+        h->use_wino = std::strcmp(algo, "direct") != 0;
+        if (std::strcmp(algo, "wino64") == 0) h->wino_bn = 64;
+    }
     std::vector<float> host;
     auto reserve = [&](size_t n) {
         const size_t at = host.size();
@@ -349,8 +388,13 @@ int adn_unet_create(adn_unet **handle, int device, const float *const *t, int n_
         Conv3x3Layer &L = h->c3[li++];
         L.Cin = Cin;
         L.Cout = Cout;
-        L.w_off = reserve((size_t)9 * Cin * Cout);
-        pack_conv3x3(t[ti], scale, Cin, Cout, host.data() + L.w_off);
+        if (h->use_wino) {
+            L.w_off = reserve((size_t)16 * Cin * Cout);
+            pack_wino3x3(t[ti], scale, Cin, Cout, h->wino_bn, host.data() + L.w_off);
+        } else {
+            L.w_off = reserve((size_t)9 * Cin * Cout);
+            pack_conv3x3(t[ti], scale, Cin, Cout, host.data() + L.w_off);
+        }
         L.b_off = reserve(Cout);
         std::memcpy(host.data() + L.b_off, bias.data(), sizeof(float) * Cout);
         ti += 6;

@@ -109,17 +109,25 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_f32(const ConvArgs p)
         const float *src_ = first_ ? base0 + (c) * KC : base1 + ((c) - p.nchunk0) * KC;        \
         _Pragma("unroll") for (int r = 0; r < A_ROUNDS; ++r) {                                 \
             const int off_ = first_ ? aoff0[r] : aoff1[r];                                     \
-            f32x4 v_ = {0.f, 0.f, 0.f, 0.f};                                                   \
-            if (off_ >= 0) v_ = *reinterpret_cast<const f32x4 *>(src_ + off_);                 \
+            /* unconditional load from a clamped (always valid) offset, then select: a load under   */ \
+            /* a branch makes hipcc wait vmcnt(0) after EACH one, serialising the prefetch          */ \
+            f32x4 v_ = *reinterpret_cast<const f32x4 *>(src_ + (off_ >= 0 ? off_ : 0));             \
+            if (off_ < 0) v_ = f32x4{0.f, 0.f, 0.f, 0.f};                                          \
             ra[r] = v_;                                                                        \
         }                                                                                      \
         const float *w_ = wbase + (size_t)(c) * B_FLOATS;                                      \
         _Pragma("unroll") for (int r = 0; r < B_ROUNDS; ++r) {                                 \
             const int item_ = tid + r * NTHREADS;                                              \
-            if ((B_ITEMS % NTHREADS == 0) || item_ < B_ITEMS)                                  \
-                rb[r] = *reinterpret_cast<const f32x4 *>(w_ + item_ * 4);                      \
+            const int citem_ = (B_ITEMS % NTHREADS == 0 || item_ < B_ITEMS) ? item_ : 0;       \
+            rb[r] = *reinterpret_cast<const f32x4 *>(w_ + citem_ * 4);   /* no branch, see above */ \
         }                                                                                      \
     } while (0)
+
+    // bias is fetched BEFORE the main loop: a load still pending in the epilogue makes hipcc wait vmcnt(0) inside
+    // every bounds-checked store block, which serialises the stores behind one another
+    float bias_r[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) bias_r[j] = p.bias[ct * BN + (wn * NB + j) * 32 + l31];
 
     f32x16 acc[MB][NB];
 #pragma unroll
@@ -178,7 +186,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_f32(const ConvArgs p)
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         const int col = ct * BN + (wn * NB + j) * 32 + l31;     // GEMM column
-        const float bv = p.bias[col];
+        const float bv = bias_r[j];
 #pragma unroll
         for (int i = 0; i < MB; ++i) {
             const int trow0 = (wm * MB + i) * 2;
