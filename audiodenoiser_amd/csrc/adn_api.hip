@@ -58,6 +58,8 @@ struct adn_unet {
     int timing_max = 0, timing_count = 0;
     bool use_wino = true;          // 3x3 layers: Winograd F(2x2,3x3) kernel (false: direct implicit GEMM)
     int wino_bn = 32;              // couts per Winograd workgroup (32: two 4-wave workgroups per CU; 64: one 8-wave)
+    bool wino_dma = true;          // stage through LDS-DMA (global_load_lds) instead of VGPRs
+    size_t zeros_off = 0;          // 64 zero floats inside the packed buffer
 };
 
 namespace {
@@ -202,12 +204,13 @@ adn::ConvArgs conv_args(const adn_unet *h, const Conv3x3Layer &L, adn::ConvKind 
     a.tilesX = (W + 15) / 16;
     a.nct = L.Cout / g.BN;
     a.ablate = 0;
+    a.zeros = h->dev + h->zeros_off;
     return a;
 }
 
 hipError_t launch_conv3(const adn_unet *h, adn::ConvKind kind, const adn::ConvArgs &a, hipStream_t st)
 {
-    return h->use_wino ? adn::launch_wino_conv(kind, a, h->wino_bn, st) : adn::launch_conv_mfma(kind, a, st);
+    return h->use_wino ? adn::launch_wino_conv(kind, a, h->wino_bn, h->wino_dma, st) : adn::launch_conv_mfma(kind, a, st);
 }
 
 int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, void *workspace, size_t ws_bytes,
@@ -297,6 +300,7 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
         t.tilesX = (uw + 15) / 16;
         t.nct = 4 * co / g.BN;
         t.ablate = 0;
+        t.zeros = h->dev + h->zeros_off;
         ADN_MARK();
         ADN_HIP(adn::launch_conv_mfma(adn::CONVT2X2, t, st));
         // first conv of the DoubleConv reads cat([skip, x1]) virtually
@@ -372,6 +376,7 @@ int adn_unet_create(adn_unet **handle, int device, const float *const *t, int n_
     if (const char *algo = std::getenv("ADN_CONV_ALGO")) {      // experiment switch: direct | wino32 | wino64
         h->use_wino = std::strcmp(algo, "direct") != 0;
         if (std::strcmp(algo, "wino64") == 0) h->wino_bn = 64;
+        if (std::strcmp(algo, "wino32r") == 0 || h->wino_bn == 64) h->wino_dma = false;   // register-staged variants
     }
     std::vector<float> host;
     auto reserve = [&](size_t n) {
@@ -380,6 +385,7 @@ int adn_unet_create(adn_unet **handle, int device, const float *const *t, int n_
         return at;
     };
     std::vector<float> scale, bias;
+    h->zeros_off = reserve(64);
 
     // tensor table walk (state_dict order, see adn.h)
     int ti = 0, li = 0;

@@ -26,6 +26,7 @@ struct ConvArgs {
     int Cout;              // output channels of the layer (GEMM columns = Cout, or 4*Cout for convT)
     int tilesY, tilesX, nct;
     int ablate;            // timing experiments only (ADN_WINO_ABLATE); 0 in production
+    const float *zeros;    // >= 16 bytes of zeros in device memory (source of padding lanes of the LDS-DMA copy)
 };
 
 enum ConvKind { CONV3X3_RELU = 0, CONV3X3_RELU_POOL = 1, CONVT2X2 = 2 };
@@ -41,7 +42,7 @@ size_t conv_packed_floats_per_chunk(ConvKind kind, int Cout);   // per (column t
 
 hipError_t launch_conv_mfma(ConvKind kind, const ConvArgs &a, hipStream_t st);
 // Winograd F(2x2,3x3) variant of the 3x3 kinds (wino_kernels.hip): tile 16x16 px x 64 couts, 8-channel chunks.
-hipError_t launch_wino_conv(ConvKind kind, const ConvArgs &a, int bn, hipStream_t st);
+hipError_t launch_wino_conv(ConvKind kind, const ConvArgs &a, int bn, bool dma, hipStream_t st);
 
 // First layer: Conv2d(1 -> 64, 3x3, pad 1) + folded BN + ReLU, NHWC output.  w9x64: [tap][cout].
 hipError_t launch_conv_first(const float *x, const float *w9x64, const float *bias, float *out,

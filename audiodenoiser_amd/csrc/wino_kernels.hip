@@ -149,6 +149,12 @@ __global__ __launch_bounds__(256 * NWN, 2) void wino_conv_f32(const ConvArgs p)
         const float *sB = sA + WA_FLOATS;
         // 4x4 input patch, two channels per lane; V = B^T d B
         f32x2 d[4][4];
+        if (p.ablate & 8) {                                // ablate&8: no patch reads
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) d[a][b] = f32x2{(float)(a + c), (float)b};
+        } else
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -195,10 +201,10 @@ __global__ __launch_bounds__(256 * NWN, 2) void wino_conv_f32(const ConvArgs p)
         }
         // stage chunk c+1 into the other image (nobody reads it now), fetch chunk c+2, then flip
         if (c + 1 < p.nchunk) {
-            if (!(p.ablate & 4)) ADN_WSTAGE((c + 1) & 1);   // ablate&4: no LDS staging writes
+            if (!(p.ablate & 4) || c < 1) ADN_WSTAGE((c + 1) & 1);   // ablate&4: no LDS staging writes after the first
             if (c + 2 < p.nchunk && !(p.ablate & 1)) ADN_WPREFETCH(c + 2);   // ablate&1: no global traffic in the loop
         }
-        __syncthreads();
+        if (!(p.ablate & 16)) __syncthreads();             // ablate&16: no barrier (races; timing only)
     }
 #undef ADN_WPREFETCH
 #undef ADN_WSTAGE
@@ -245,6 +251,224 @@ __global__ __launch_bounds__(256 * NWN, 2) void wino_conv_f32(const ConvArgs p)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA variant (default): same tiling as wino_conv_f32<EPI, 1> (4 waves, 16x16 px x 32 couts, two
+// workgroups per CU) but the halo and the U slab are copied global -> LDS directly with
+// global_load_lds_dwordx4 (1 KiB per wave instruction, no VGPR staging, no ds_write pass).  The copy of chunk
+// c+1 is issued BEFORE chunk c's MFMAs and lands under them; one barrier per chunk.
+//   LDS image (x2): halo rows of 55 sixteen-byte slots (18 pixels x [8 ch = 2 slots + 1 pad slot] + 1 pad),
+//   990 slots padded to 1024, then the U slab [pos][q][n][2] = 1024 slots -> 8 DMA rounds of 256 lanes.
+//   Lanes of pad / out-of-image slots read a 16-byte zero block (conv zero padding comes for free).
+// ------------------------------------------------------------------------------------------------
+constexpr int DROW = 220;                 // halo row pitch in floats (55 slots)
+constexpr int DHALO_SLOTS = 1024;
+constexpr int DU_SLOTS = 1024;
+constexpr int DBUF = (DHALO_SLOTS + DU_SLOTS) * 4;   // floats per image
+
+__device__ __forceinline__ void dma16(const float *g, float *lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_conv_dma_f32(const ConvArgs p)
+{
+    constexpr int WBN = 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // the ONLY LDS object (two images)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform (DMA base, tile row pair)
+    const int wm = wave;
+    const int ti = lane & 15, q = lane >> 4;
+
+    int lid = wino_xcd_remap(blockIdx.x, gridDim.x);
+    const int ct = lid % p.nct;
+    lid /= p.nct;
+    const int tx = lid % p.tilesX;
+    lid /= p.tilesX;
+    const int ty = lid % p.tilesY;
+    const int n = lid / p.tilesY;
+    const int gy0 = ty * WT - 1, gx0 = tx * WT - 1;
+
+    // ---- DMA plan: halo slot s = r*256 + tid  ->  (row, pixel, 16-byte part) ----
+    // hcur = offsets into the source of the NEXT chunk to copy; hsec = offsets into the second source (virtual
+    // concat).  Two plain arrays switched once at chunk nchunk0 (a `first ? a[r] : b[r]` select makes hipcc build
+    // a runtime-indexed stack array: scratch loads, and a vmcnt(0) wait that also drains the DMA just issued).
+    int hcur[4], hsec[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int s = r * 256 + tid;
+        const int row = s / 55, k = s - row * 55;
+        const int pix = k / 3, part = k - pix * 3;
+        const bool data = s < 18 * 55 && part < 2 && pix < WP;
+        const int gy = gy0 + row, gx = gx0 + pix;
+        const int y0 = gy - p.s0.offY, x0 = gx - p.s0.offX;
+        hcur[r] = (data && y0 >= 0 && y0 < p.s0.H && x0 >= 0 && x0 < p.s0.W) ? (y0 * p.s0.W + x0) * p.s0.C + part * 4 : -1;
+        const int y1 = gy - p.s1.offY, x1 = gx - p.s1.offX;
+        hsec[r] = (data && y1 >= 0 && y1 < p.s1.H && x1 >= 0 && x1 < p.s1.W) ? (y1 * p.s1.W + x1) * p.s1.C + part * 4 : -1;
+    }
+    const float *srcp = p.s0.ptr + (size_t)n * p.s0.H * p.s0.W * p.s0.C;    // channel window of the next chunk
+    const float *base1 = p.s1.ptr + (size_t)n * p.s1.H * p.s1.W * p.s1.C;
+    const float *wp = p.wpk + (size_t)ct * p.nchunk * (DU_SLOTS * 4) + tid * 4;
+    const float *zsrc = p.zeros;
+
+#define ADN_DMA(c, buf)                                                                        \
+    do {                                                                                       \
+        if ((c) == p.nchunk0) {                       /* wave-uniform: switch to the second source */ \
+            srcp = base1;                                                                      \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) hcur[r] = hsec[r];                   \
+        }                                                                                      \
+        float *dst_ = smem + (buf) * DBUF + wave * 256;                                        \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r)                                          \
+            dma16(hcur[r] >= 0 ? srcp + hcur[r] : zsrc, dst_ + r * 1024);                      \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) dma16(wp + r * 1024, dst_ + DHALO_SLOTS * 4 + r * 1024); \
+        srcp += WKC;                                                                           \
+        wp += DU_SLOTS * 4;                                                                    \
+    } while (0)
+
+    float bias_r[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bias_r[j] = p.bias[ct * WBN + 16 * j + ti];
+
+    f32x4 acc[2][16];                                  // [cout block of 16][winograd position]
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc[j][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // patch reads: lane-varying dword offset = 440*(ti>>3) + 24*(ti&7) + 2q -> at most 2-way conflicts (the 16-byte
+    // slot grid forbids the conflict-free pitch of the register-staged variant); volatile keeps single ds_read_b64.
+    const int a_lane = (2 * (2 * wm + (ti >> 3))) * DROW + 2 * (ti & 7) * WASTR + 2 * q;
+    const int b_lane = (q * WBN + ti) * 2;
+
+    ADN_DMA(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int c = 0; c < p.nchunk; ++c) {
+        if (c + 1 < p.nchunk) ADN_DMA(c + 1, (c + 1) & 1);     // lands under this chunk's MFMAs
+        const float *sA = smem + (c & 1) * DBUF;
+        const float *sB = sA + DHALO_SLOTS * 4;
+        f32x2 d[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) d[a][b] = *(lds_cv_f32x2 *)(sA + a_lane + a * DROW + b * WASTR);
+        f32x2 t[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            t[a][0] = d[a][0] - d[a][2];
+            t[a][1] = d[a][1] + d[a][2];
+            t[a][2] = d[a][2] - d[a][1];
+            t[a][3] = d[a][1] - d[a][3];
+        }
+        f32x2 V[16];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            V[0 * 4 + v] = t[0][v] - t[2][v];
+            V[1 * 4 + v] = t[1][v] + t[2][v];
+            V[2 * 4 + v] = t[2][v] - t[1][v];
+            V[3 * 4 + v] = t[1][v] - t[3][v];
+        }
+        // B fragments are fetched one position-group ahead of the MFMAs that consume them (explicit ping-pong:
+        // left to itself hipcc issues read -> lgkmcnt(0) -> 4 MFMAs per position, exposing the LDS latency)
+        f32x2 ua[2][4], ub[2][4];
+#define ADN_LOADU(dst, g)                                                                               \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                   \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                   \
+            dst[j][s] = *reinterpret_cast<const f32x2 *>(sB + b_lane + 32 * j + (4 * (g) + s) * (4 * WBN * 2))
+#define ADN_MFMAS(src, g)                                                                               \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                   \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                   \
+            acc[j][4 * (g) + s] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[4 * (g) + s].x, src[j][s].x, acc[j][4 * (g) + s], 0, 0, 0); \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                   \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                   \
+            acc[j][4 * (g) + s] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[4 * (g) + s].y, src[j][s].y, acc[j][4 * (g) + s], 0, 0, 0)
+        ADN_LOADU(ua, 0);
+        ADN_LOADU(ub, 1);
+        __builtin_amdgcn_sched_barrier(0);      // nothing crosses: keeps the reads one group ahead of their MFMAs
+        ADN_MFMAS(ua, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        ADN_LOADU(ua, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        ADN_MFMAS(ub, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        ADN_LOADU(ub, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        ADN_MFMAS(ua, 2);
+        ADN_MFMAS(ub, 3);
+#undef ADN_LOADU
+#undef ADN_MFMAS
+        // every wave: its own DMA writes have landed (vmcnt) ; then all waves: image c is free, image c+1 complete
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#undef ADN_DMA
+
+    const int Hp = p.H >> 1, Wp = p.W >> 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = ct * WBN + 16 * j + ti;
+        const float bv = bias_r[j];
+        float *ob = p.out + (size_t)n * p.H * p.W * p.Cout + col;
+        float *pb = (EPI == CONV3X3_RELU_POOL) ? p.pool + (size_t)n * Hp * Wp * p.Cout + col : nullptr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int tile = 4 * q + r;
+            const int tyw = 2 * wm + (tile >> 3), txw = tile & 7;
+            float s0[4], s1[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                s0[x] = acc[j][4 * x + 0][r] + acc[j][4 * x + 1][r] + acc[j][4 * x + 2][r];
+                s1[x] = acc[j][4 * x + 1][r] - acc[j][4 * x + 2][r] - acc[j][4 * x + 3][r];
+            }
+            float y[2][2];
+            y[0][0] = s0[0] + s0[1] + s0[2];
+            y[1][0] = s0[1] - s0[2] - s0[3];
+            y[0][1] = s1[0] + s1[1] + s1[2];
+            y[1][1] = s1[1] - s1[2] - s1[3];
+            const int gy = ty * WT + 2 * tyw, gx = tx * WT + 2 * txw;
+            float mx = 0.f;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const float v = fmaxf(y[a][b] + bv, 0.f);
+                    mx = fmaxf(mx, v);
+                    if (gy + a < p.H && gx + b < p.W) ob[((size_t)(gy + a) * p.W + gx + b) * p.Cout] = v;
+                }
+            if (EPI == CONV3X3_RELU_POOL) {
+                const int py = gy >> 1, px = gx >> 1;
+                if (py < Hp && px < Wp) pb[((size_t)py * Wp + px) * p.Cout] = mx;
+            }
+        }
+    }
+}
+
+hipError_t launch_wino_dma(ConvKind kind, const ConvArgs &a, hipStream_t st)
+{
+    constexpr size_t lds = (size_t)2 * DBUF * sizeof(float);   // 65536 B
+    const long nwg = (long)a.N * a.tilesY * a.tilesX * a.nct;
+    if (nwg <= 0 || nwg > 0x7fffffffL) return hipErrorInvalidValue;
+    if (!a.zeros) return hipErrorInvalidValue;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_conv_dma_f32<CONV3X3_RELU_POOL>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_conv_dma_f32<CONV3X3_RELU>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e1 != hipSuccess) return e1;
+        if (e2 != hipSuccess) return e2;
+        attr_done = true;
+    }
+    if (kind == CONV3X3_RELU_POOL)
+        hipLaunchKernelGGL((wino_conv_dma_f32<CONV3X3_RELU_POOL>), dim3((unsigned)nwg), dim3(256), lds, st, a);
+    else
+        hipLaunchKernelGGL((wino_conv_dma_f32<CONV3X3_RELU>), dim3((unsigned)nwg), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
 template <int NWN>
 hipError_t launch_wino_n(ConvKind kind, const ConvArgs &a, hipStream_t st)
 {
@@ -276,8 +500,9 @@ hipError_t launch_wino_n(ConvKind kind, const ConvArgs &a, hipStream_t st)
 }  // namespace
 
 // bn = output channels per workgroup (32 or 64); must match the packing done by adn_api.hip::pack_wino3x3
-hipError_t launch_wino_conv(ConvKind kind, const ConvArgs &a, int bn, hipStream_t st)
+hipError_t launch_wino_conv(ConvKind kind, const ConvArgs &a, int bn, bool dma, hipStream_t st)
 {
+    if (bn == 32 && dma) return launch_wino_dma(kind, a, st);
     return bn == 32 ? launch_wino_n<1>(kind, a, st) : launch_wino_n<2>(kind, a, st);
 }
 
