@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int c = 0; c < p.nchunk; ++c) {
-        if (c + 1 < p.nchunk) ADN_DMA(c + 1, (c + 1) & 1);     // lands under this chunk's MFMAs
+        if (c + 1 < p.nchunk && !((p.ablate & 1) && c >= 1)) ADN_DMA(c + 1, (c + 1) & 1);   // lands under this chunk's MFMAs (ablate&1: timing experiment)
         const float *sA = smem + (c & 1) * DBUF;
         const float *sB = sA + DHALO_SLOTS * 4;
         f32x2 d[4][4];
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #undef ADN_MFMAS
         // every wave: its own DMA writes have landed (vmcnt) ; then all waves: image c is free, image c+1 complete
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (!(p.ablate & 16)) __syncthreads();             // ablate&16: timing experiment (races)
     }
 #undef ADN_DMA
 
@@ -452,6 +452,11 @@ hipError_t launch_wino_dma(ConvKind kind, const ConvArgs &a, hipStream_t st)
     const long nwg = (long)a.N * a.tilesY * a.tilesX * a.nct;
     if (nwg <= 0 || nwg > 0x7fffffffL) return hipErrorInvalidValue;
     if (!a.zeros) return hipErrorInvalidValue;
+    ConvArgs a2 = a;
+    {
+        const char *ab = std::getenv("ADN_WINO_ABLATE");
+        a2.ablate = ab ? std::atoi(ab) : 0;
+    }
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_conv_dma_f32<CONV3X3_RELU_POOL>),
@@ -463,9 +468,9 @@ hipError_t launch_wino_dma(ConvKind kind, const ConvArgs &a, hipStream_t st)
         attr_done = true;
     }
     if (kind == CONV3X3_RELU_POOL)
-        hipLaunchKernelGGL((wino_conv_dma_f32<CONV3X3_RELU_POOL>), dim3((unsigned)nwg), dim3(256), lds, st, a);
+        hipLaunchKernelGGL((wino_conv_dma_f32<CONV3X3_RELU_POOL>), dim3((unsigned)nwg), dim3(256), lds, st, a2);
     else
-        hipLaunchKernelGGL((wino_conv_dma_f32<CONV3X3_RELU>), dim3((unsigned)nwg), dim3(256), lds, st, a);
+        hipLaunchKernelGGL((wino_conv_dma_f32<CONV3X3_RELU>), dim3((unsigned)nwg), dim3(256), lds, st, a2);
     return hipGetLastError();
 }
 

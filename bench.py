@@ -10,11 +10,14 @@ synthetic 513x256 fp32 spectrograms) + the per-clip L1 kernel, and for N > 1 the
 per-clip values (clips shard over ranks, weights replicated, no data-path collective; weak scaling: the batch
 per GPU is fixed).  Rank 0 prints ONE JSON line; `value` = all ranks' frames / max-over-ranks time.
 
-roofline: the dominant kernel is conv_mfma_f32 (the 17 fp32-MFMA 3x3 convolutions, 95 % of the FLOPs).  Its
-launches are bracketed with hipEvents on the launch stream inside libadn (adn_unet_set_timing) during the timed
-steps; achieved = algorithmic FLOPs of those launches / their summed duration (= average FLOPs per launch /
-average launch duration), peak = 157.3 TFLOP/s (fp32 MFMA, MI355X_MICROARCH.md).  `traffic` (HBM bytes per
-launch from rocprofv3 PMC passes) is read from profiles/pmc_traffic.json when that file has been produced.
+roofline: the dominant kernel is wino_conv_dma_f32 (the 17 3x3 convolutions, 95 % of the FLOPs; Winograd
+F(2x2,3x3) on the fp32 matrix cores; ADN_CONV_ALGO=direct selects the direct implicit-GEMM kernel conv_mfma_f32).
+Its launches are bracketed with hipEvents on the launch stream inside libadn (adn_unet_set_timing) during the timed
+steps; achieved = ALGORITHMIC (direct-convolution) FLOPs of those launches / their summed duration (= average
+FLOPs per launch / average launch duration), peak = 157.3 TFLOP/s (fp32 MFMA, MI355X_MICROARCH.md).  Winograd
+executes 1/2.25 of the algorithmic FLOPs on the matrix cores, so `frac` may exceed 1; `mfma_util` is the share of
+the matrix-core peak actually executed.  `traffic` (HBM bytes per launch from rocprofv3 PMC passes) is read from
+profiles/pmc_traffic.json when that file has been produced.
 
 cpu_baseline: the oracle's torch.nn.functional restatement of the reference forward (same ATen/oneDNN kernels
 the reference's model.py dispatches to; kind "port") timed on this host's cores on a bounded sample.
@@ -168,7 +171,7 @@ def main() -> None:
         if os.path.exists(tpath):
             try:
                 with open(tpath) as fh:
-                    traffic = json.load(fh).get("conv_mfma_f32_bytes_per_launch")
+                    traffic = json.load(fh).get("dominant_bytes_per_launch")
             except (OSError, ValueError):
                 traffic = None
         frames = b * world * T_FRAMES * args.steps
@@ -191,7 +194,10 @@ def main() -> None:
                        "parallelism": f"clips sharded over {world} rank(s), weights replicated"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_MFMA_F32_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_F32_TFLOPS, 4), "traffic": traffic,
-                         "kernel": "conv_mfma_f32 (17 fp32-MFMA 3x3 conv launches per forward)",
+                         "kernel": ("conv_mfma_f32 (direct implicit GEMM)" if os.environ.get("ADN_CONV_ALGO") == "direct"
+                                    else "wino_conv_dma_f32 (Winograd F(2x2,3x3), fp32 MFMA)") + ", 17 launches per forward",
+                         "mfma_util": round(achieved / PEAK_MFMA_F32_TFLOPS /
+                                            (1.0 if os.environ.get("ADN_CONV_ALGO") == "direct" else 2.25), 4),
                          "flops_per_launch": round(dom_flops / len(dom), 1),
                          "avg_launch_ms": round(dom_ms / len(dom), 4)},
             "forward": {"kernel_ms": round(fwd_ms, 3),

@@ -46,8 +46,8 @@ def main():
     ap.add_argument("--tag", default="r01")
     ap.add_argument("--out", default="profiles")
     ap.add_argument("--cmd", default="python bench.py --steps 5 --warmup 2 --no-cpu-baseline")
-    ap.add_argument("--dominant", default="conv_mfma_f32", help="kernel-name prefix of the dominant kernel")
-    ap.add_argument("--dominant-filter", default=", 9, 1, ", help="substring selecting its instantiations")
+    ap.add_argument("--dominant", default="wino_conv_dma_f32", help="kernel-name prefix of the dominant kernel")
+    ap.add_argument("--dominant-filter", default="", help="substring selecting its instantiations")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     lines = []
@@ -94,11 +94,12 @@ def main():
                 agg[0] += len(f)
                 agg[1] += (fb + wb) * len(f)
         if agg[0]:
-            traffic[f"{args.dominant}_bytes_per_launch"] = round(agg[1] / agg[0])
+            traffic["dominant_bytes_per_launch"] = round(agg[1] / agg[0])
+            traffic["dominant_kernel"] = args.dominant
             traffic["note"] = ("mean over the dominant kernel's dispatches of bench.py (batch 64): (2*FETCH_SIZE + "
                                "WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes; the x2 is the gfx950 FETCH_SIZE "
                                "correction of MI355X_MICROARCH.md")
-            lines.append(f"{args.dominant} mean HBM bytes per launch: {traffic[args.dominant + '_bytes_per_launch']}")
+            lines.append(f"{args.dominant} mean HBM bytes per launch: {traffic['dominant_bytes_per_launch']}")
     with open(os.path.join(args.out, f"{args.tag}_rocprof_summary.txt"), "w") as fh:
         fh.write("\n".join(lines) + "\n")
     if traffic:
