@@ -205,6 +205,7 @@ adn::ConvArgs conv_args(const adn_unet *h, const Conv3x3Layer &L, adn::ConvKind 
     a.nct = L.Cout / g.BN;
     a.ablate = 0;
     a.zeros = h->dev + h->zeros_off;
+    a.dbg = nullptr;
     return a;
 }
 
@@ -301,6 +302,7 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
         t.nct = 4 * co / g.BN;
         t.ablate = 0;
         t.zeros = h->dev + h->zeros_off;
+        t.dbg = nullptr;
         ADN_MARK();
         ADN_HIP(adn::launch_conv_mfma(adn::CONVT2X2, t, st));
         // first conv of the DoubleConv reads cat([skip, x1]) virtually

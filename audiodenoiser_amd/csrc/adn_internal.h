@@ -27,6 +27,7 @@ struct ConvArgs {
     int tilesY, tilesX, nct;
     int ablate;            // timing experiments only (ADN_WINO_ABLATE); 0 in production
     const float *zeros;    // >= 16 bytes of zeros in device memory (source of padding lanes of the LDS-DMA copy)
+    void *dbg;             // diagnostic stamp buffer (ADN_WINO_STAMP); nullptr in production
 };
 
 enum ConvKind { CONV3X3_RELU = 0, CONV3X3_RELU_POOL = 1, CONVT2X2 = 2 };

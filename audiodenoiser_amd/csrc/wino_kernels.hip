@@ -20,7 +20,9 @@
 //   inside an MFMA is free: A and B only have to agree).
 #include "adn_internal.h"
 
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 namespace adn {
 
@@ -260,49 +262,73 @@ __global__ __launch_bounds__(256 * NWN, 2) void wino_conv_f32(const ConvArgs p)
 //   990 slots padded to 1024, then the U slab [pos][q][n][2] = 1024 slots -> 8 DMA rounds of 256 lanes.
 //   Lanes of pad / out-of-image slots read a 16-byte zero block (conv zero padding comes for free).
 // ------------------------------------------------------------------------------------------------
-constexpr int DROW = 220;                 // halo row pitch in floats (55 slots)
-constexpr int DHALO_SLOTS = 1024;
-constexpr int DU_SLOTS = 1024;
-constexpr int DBUF = (DHALO_SLOTS + DU_SLOTS) * 4;   // floats per image
-
 __device__ __forceinline__ void dma16(const float *g, float *lds_wave_base)
 {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
-template <int EPI>
-__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_conv_dma_f32(const ConvArgs p)
+// Geometry of the LDS-DMA kernel for NW waves (4: 16x16 px, two workgroups per CU; 8: 16x32 px, one per CU).
+// The 8-wave tile halves the bytes staged per MFMA (U slab shared by twice the pixels): the kernel is bound by
+// the CU's ~12 B/clk ingest rate, not by the matrix cores, so bytes per MFMA is what matters.
+template <int NW>
+struct DmaGeom {
+    static constexpr int NT = 64 * NW;
+    static constexpr int TWT = NW == 8 ? 16 : 8;           // winograd tiles per tile row
+    static constexpr int TPW = 2 * TWT;                    // output pixels per tile row
+    static constexpr int HW = TPW + 2;                     // halo columns
+    static constexpr int SPP = 2;                          // 16-byte slots per halo pixel (8 channels, no pad slot)
+    static constexpr int PSTR = SPP * 4;                   // floats per halo pixel
+    static constexpr int RSLOTS = HW * SPP + 1;            // slots per halo row (+1 pad)
+    static constexpr int DROW = RSLOTS * 4;                // floats per halo row
+    static constexpr int HUSED = WP * RSLOTS;              // slots that carry the halo
+    static constexpr int HR = (HUSED + NT - 1) / NT;       // DMA rounds for the halo
+    static constexpr int UR = 1024 / NT;                   // DMA rounds for the U slab (16 pos x 8 ch x 32 couts)
+    static constexpr int DBUF = (HR + UR) * NT * 4;        // floats per LDS image
+    static constexpr int SUP = NW == 8 ? 32 : 64;          // workgroups resident on one XCD
+};
+
+template <int EPI, int NW>
+__global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_conv_dma_f32(const ConvArgs p)
 {
-    constexpr int WBN = 32;
+    using G = DmaGeom<NW>;
+    constexpr int WBN = 32, NT = G::NT, HR = G::HR, UR = G::UR, DBUF = G::DBUF, DROW = G::DROW, PSTR = G::PSTR;
     extern __shared__ __attribute__((aligned(16))) float smem[];   // the ONLY LDS object (two images)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform (DMA base, tile row pair)
-    const int wm = wave;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform (DMA base, tile block)
+    const int wr = NW == 8 ? wave >> 1 : wave;                     // tile-row pair
+    const int wc = NW == 8 ? wave & 1 : 0;                         // block of 8 tile columns
     const int ti = lane & 15, q = lane >> 4;
 
+    // Workgroup -> (pixel tile, cout tile).  After the XCD remap, SUP consecutive ids run together on one XCD;
+    // they form a supertile of gc cout tiles x gp pixel tiles so that every U slab and every halo is fetched into
+    // that XCD's L2 once and hit by the other workgroups of the supertile.
     int lid = wino_xcd_remap(blockIdx.x, gridDim.x);
-    const int ct = lid % p.nct;
-    lid /= p.nct;
-    const int tx = lid % p.tilesX;
-    lid /= p.tilesX;
-    const int ty = lid % p.tilesY;
-    const int n = lid / p.tilesY;
-    const int gy0 = ty * WT - 1, gx0 = tx * WT - 1;
+    const int gc = p.nct < 8 ? p.nct : 8, gp = G::SUP / gc;
+    const int ncg = p.nct / gc;
+    const int sg = lid / G::SUP, wl = lid - sg * G::SUP;
+    const int ct = (sg % ncg) * gc + wl % gc;
+    int pt = (sg / ncg) * gp + wl / gc;
+    if (pt >= p.N * p.tilesY * p.tilesX) return;          // padding of the last supertile (whole workgroup exits)
+    const int tx = pt % p.tilesX;
+    pt /= p.tilesX;
+    const int ty = pt % p.tilesY;
+    const int n = pt / p.tilesY;
+    const int gy0 = ty * WT - 1, gx0 = tx * G::TPW - 1;
 
-    // ---- DMA plan: halo slot s = r*256 + tid  ->  (row, pixel, 16-byte part) ----
+    // ---- DMA plan: halo slot s = r*NT + tid  ->  (row, pixel, 16-byte part) ----
     // hcur = offsets into the source of the NEXT chunk to copy; hsec = offsets into the second source (virtual
     // concat).  Two plain arrays switched once at chunk nchunk0 (a `first ? a[r] : b[r]` select makes hipcc build
     // a runtime-indexed stack array: scratch loads, and a vmcnt(0) wait that also drains the DMA just issued).
-    int hcur[4], hsec[4];
+    int hcur[HR], hsec[HR];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int s = r * 256 + tid;
-        const int row = s / 55, k = s - row * 55;
-        const int pix = k / 3, part = k - pix * 3;
-        const bool data = s < 18 * 55 && part < 2 && pix < WP;
+    for (int r = 0; r < HR; ++r) {
+        const int s = r * NT + tid;
+        const int row = s / G::RSLOTS, k = s - row * G::RSLOTS;
+        const int pix = k / G::SPP, part = k - pix * G::SPP;
+        const bool data = s < G::HUSED && part < 2 && pix < G::HW;
         const int gy = gy0 + row, gx = gx0 + pix;
         const int y0 = gy - p.s0.offY, x0 = gx - p.s0.offX;
         hcur[r] = (data && y0 >= 0 && y0 < p.s0.H && x0 >= 0 && x0 < p.s0.W) ? (y0 * p.s0.W + x0) * p.s0.C + part * 4 : -1;
@@ -311,21 +337,33 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     }
     const float *srcp = p.s0.ptr + (size_t)n * p.s0.H * p.s0.W * p.s0.C;    // channel window of the next chunk
     const float *base1 = p.s1.ptr + (size_t)n * p.s1.H * p.s1.W * p.s1.C;
-    const float *wp = p.wpk + (size_t)ct * p.nchunk * (DU_SLOTS * 4) + tid * 4;
+    const float *wp = p.wpk + (size_t)ct * p.nchunk * 4096 + tid * 4;
     const float *zsrc = p.zeros;
 
-#define ADN_DMA(c, buf)                                                                        \
+#define ADN_DMA_BEGIN(c)                                                                       \
     do {                                                                                       \
         if ((c) == p.nchunk0) {                       /* wave-uniform: switch to the second source */ \
             srcp = base1;                                                                      \
-            _Pragma("unroll") for (int r = 0; r < 4; ++r) hcur[r] = hsec[r];                   \
+            _Pragma("unroll") for (int r = 0; r < HR; ++r) hcur[r] = hsec[r];                  \
         }                                                                                      \
-        float *dst_ = smem + (buf) * DBUF + wave * 256;                                        \
-        _Pragma("unroll") for (int r = 0; r < 4; ++r)                                          \
-            dma16(hcur[r] >= 0 ? srcp + hcur[r] : zsrc, dst_ + r * 1024);                      \
-        _Pragma("unroll") for (int r = 0; r < 4; ++r) dma16(wp + r * 1024, dst_ + DHALO_SLOTS * 4 + r * 1024); \
+    } while (0)
+    // piece k of the HR + UR wave-instructions that copy chunk c into image buf
+#define ADN_DMA_PIECE(k, buf)                                                                  \
+    do {                                                                                       \
+        float *dst_ = smem + (buf) * DBUF + wave * 256 + (k) * NT * 4;                         \
+        if ((k) < HR) dma16(hcur[(k) < HR ? (k) : 0] >= 0 ? srcp + hcur[(k) < HR ? (k) : 0] : zsrc, dst_); \
+        else dma16(wp + ((k) - HR) * NT * 4, dst_);                                            \
+    } while (0)
+#define ADN_DMA_END()                                                                          \
+    do {                                                                                       \
         srcp += WKC;                                                                           \
-        wp += DU_SLOTS * 4;                                                                    \
+        wp += 4096;                                                                            \
+    } while (0)
+#define ADN_DMA(c, buf)                                                                        \
+    do {                                                                                       \
+        ADN_DMA_BEGIN(c);                                                                      \
+        _Pragma("unroll") for (int k = 0; k < HR + UR; ++k) ADN_DMA_PIECE(k, buf);             \
+        ADN_DMA_END();                                                                         \
     } while (0)
 
     float bias_r[2];
@@ -338,23 +376,46 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
         for (int s = 0; s < 16; ++s) acc[j][s] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // patch reads: lane-varying dword offset = 440*(ti>>3) + 24*(ti&7) + 2q -> at most 2-way conflicts (the 16-byte
-    // slot grid forbids the conflict-free pitch of the register-staged variant); volatile keeps single ds_read_b64.
-    const int a_lane = (2 * (2 * wm + (ti >> 3))) * DROW + 2 * (ti & 7) * WASTR + 2 * q;
+    // patch reads (volatile: single ds_read_b64 each): at most 2-way bank conflicts with either halo layout
+    const int a_lane = (2 * (2 * wr + (ti >> 3))) * DROW + 2 * (8 * wc + (ti & 7)) * PSTR + 2 * q;
     const int b_lane = (q * WBN + ti) * 2;
 
+    // diagnostic stamps (p.dbg != nullptr only; never in production): cycles per phase, summed over the chunks
+    const bool stamp = p.dbg != nullptr;
+    unsigned long long tprev = 0, tsum[6] = {0, 0, 0, 0, 0, 0};
+#define ADN_STAMP(k)                                                                         \
+    do {                                                                                     \
+        if (stamp) {                                                                         \
+            unsigned long long t_;                                                           \
+            __builtin_amdgcn_sched_barrier(0);                                               \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");       \
+            __builtin_amdgcn_sched_barrier(0);                                               \
+            tsum[k] += t_ - tprev;                                                           \
+            tprev = t_;                                                                      \
+        }                                                                                    \
+    } while (0)
     ADN_DMA(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (stamp) {
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
+    }
     for (int c = 0; c < p.nchunk; ++c) {
-        if (c + 1 < p.nchunk && !((p.ablate & 1) && c >= 1)) ADN_DMA(c + 1, (c + 1) & 1);   // lands under this chunk's MFMAs (ablate&1: timing experiment)
+        // the copy of chunk c+1 is issued in four slices between the MFMA groups below: a wave stalled in VMEM issue
+        // (back-pressure of the CU's ~12 B/clk ingest path) then overlaps its SIMD partner's MFMAs instead of
+        // delaying its own
+        const bool more = c + 1 < p.nchunk;
+        const int nb = (c + 1) & 1;
+        if (more) ADN_DMA_BEGIN(c + 1);
+        ADN_STAMP(0);
         const float *sA = smem + (c & 1) * DBUF;
-        const float *sB = sA + DHALO_SLOTS * 4;
+        const float *sB = sA + HR * NT * 4;
         f32x2 d[4][4];
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) d[a][b] = *(lds_cv_f32x2 *)(sA + a_lane + a * DROW + b * WASTR);
+            for (int b = 0; b < 4; ++b) d[a][b] = *(lds_cv_f32x2 *)(sA + a_lane + a * DROW + b * PSTR);
+        ADN_STAMP(1);                                     // patch reads landed
         f32x2 t[4][4];
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
@@ -371,8 +432,9 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             V[2 * 4 + v] = t[2][v] - t[1][v];
             V[3 * 4 + v] = t[1][v] - t[3][v];
         }
-        // B fragments are fetched one position-group ahead of the MFMAs that consume them (explicit ping-pong:
-        // left to itself hipcc issues read -> lgkmcnt(0) -> 4 MFMAs per position, exposing the LDS latency)
+        // hipcc only ever emits lgkmcnt(0) in this loop, so keep exactly ONE group of B reads in flight at each wait:
+        // read(g+1) is issued right after the wait for g (forced by an empty asm that consumes the last register of
+        // group g) and flies under group g's 16 MFMAs.  sched_barrier(0) pins the order.
         f32x2 ua[2][4], ub[2][4];
 #define ADN_LOADU(dst, g)                                                                               \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                   \
@@ -385,26 +447,70 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                   \
         _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                   \
             acc[j][4 * (g) + s] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[4 * (g) + s].y, src[j][s].y, acc[j][4 * (g) + s], 0, 0, 0)
+#define ADN_LANDED(x) asm volatile("" ::"v"(x[1][3].y))
+        ADN_STAMP(2);                                     // transform
         ADN_LOADU(ua, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        ADN_LANDED(ua);
         ADN_LOADU(ub, 1);
-        __builtin_amdgcn_sched_barrier(0);      // nothing crosses: keeps the reads one group ahead of their MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+#pragma unroll
+            for (int k = ((HR + UR) * 0) / 4; k < ((HR + UR) * 1) / 4; ++k) ADN_DMA_PIECE(k, nb);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         ADN_MFMAS(ua, 0);
         __builtin_amdgcn_sched_barrier(0);
+        ADN_LANDED(ub);
         ADN_LOADU(ua, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+#pragma unroll
+            for (int k = ((HR + UR) * 1) / 4; k < ((HR + UR) * 2) / 4; ++k) ADN_DMA_PIECE(k, nb);
+        }
         __builtin_amdgcn_sched_barrier(0);
         ADN_MFMAS(ub, 1);
         __builtin_amdgcn_sched_barrier(0);
+        ADN_LANDED(ua);
         ADN_LOADU(ub, 3);
         __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+#pragma unroll
+            for (int k = ((HR + UR) * 2) / 4; k < ((HR + UR) * 3) / 4; ++k) ADN_DMA_PIECE(k, nb);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         ADN_MFMAS(ua, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        ADN_LANDED(ub);
+        if (more) {
+#pragma unroll
+            for (int k = ((HR + UR) * 3) / 4; k < ((HR + UR) * 4) / 4; ++k) ADN_DMA_PIECE(k, nb);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         ADN_MFMAS(ub, 3);
+        __builtin_amdgcn_sched_barrier(0);      // keep the MFMAs above the DMA wait + barrier below
+        if (more) ADN_DMA_END();
+#undef ADN_LANDED
 #undef ADN_LOADU
 #undef ADN_MFMAS
+        ADN_STAMP(3);                                     // B reads + 64 MFMAs issued
         // every wave: its own DMA writes have landed (vmcnt) ; then all waves: image c is free, image c+1 complete
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (!(p.ablate & 16)) __syncthreads();             // ablate&16: timing experiment (races)
+        ADN_STAMP(4);                                     // own DMA landed
+        __syncthreads();
+        ADN_STAMP(5);                                     // barrier
     }
 #undef ADN_DMA
+#undef ADN_DMA_BEGIN
+#undef ADN_DMA_PIECE
+#undef ADN_DMA_END
+#undef ADN_STAMP
+    if (stamp && lane == 0) {
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(p.dbg) + ((size_t)blockIdx.x * NW + wave) * 8;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) o[k] = tsum[k];
+        o[6] = (unsigned long long)p.nchunk;
+    }
 
     const int Hp = p.H >> 1, Wp = p.W >> 1;
 #pragma unroll
@@ -416,7 +522,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int tile = 4 * q + r;
-            const int tyw = 2 * wm + (tile >> 3), txw = tile & 7;
+            const int tyw = 2 * wr + (tile >> 3), txw = 8 * wc + (tile & 7);
             float s0[4], s1[4];
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
@@ -428,7 +534,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             y[1][0] = s0[1] - s0[2] - s0[3];
             y[0][1] = s1[0] + s1[1] + s1[2];
             y[1][1] = s1[1] - s1[2] - s1[3];
-            const int gy = ty * WT + 2 * tyw, gx = tx * WT + 2 * txw;
+            const int gy = ty * WT + 2 * tyw, gx = tx * G::TPW + 2 * txw;
             float mx = 0.f;
 #pragma unroll
             for (int a = 0; a < 2; ++a)
@@ -446,32 +552,59 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     }
 }
 
-hipError_t launch_wino_dma(ConvKind kind, const ConvArgs &a, hipStream_t st)
+template <int NW>
+hipError_t launch_wino_dma_n(ConvKind kind, const ConvArgs &a, hipStream_t st)
 {
-    constexpr size_t lds = (size_t)2 * DBUF * sizeof(float);   // 65536 B
-    const long nwg = (long)a.N * a.tilesY * a.tilesX * a.nct;
-    if (nwg <= 0 || nwg > 0x7fffffffL) return hipErrorInvalidValue;
-    if (!a.zeros) return hipErrorInvalidValue;
+    using G = DmaGeom<NW>;
+    constexpr size_t lds = (size_t)2 * G::DBUF * sizeof(float);
     ConvArgs a2 = a;
-    {
-        const char *ab = std::getenv("ADN_WINO_ABLATE");
-        a2.ablate = ab ? std::atoi(ab) : 0;
-    }
+    a2.tilesX = (a.W + G::TPW - 1) / G::TPW;
+    // grid padded to whole supertiles (see the kernel): gp pixel tiles x gc cout tiles, gc*gp = SUP
+    const long gc = a2.nct < 8 ? a2.nct : 8, gp = G::SUP / gc;
+    const long ptiles = (long)a2.N * a2.tilesY * a2.tilesX;
+    const long nwg = ((ptiles + gp - 1) / gp) * gp * a2.nct;
+    if (nwg <= 0 || nwg > 0x7fffffffL) return hipErrorInvalidValue;
+    if (!a2.zeros) return hipErrorInvalidValue;
+    a2.ablate = 0;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_conv_dma_f32<CONV3X3_RELU_POOL>),
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_conv_dma_f32<CONV3X3_RELU_POOL, NW>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_conv_dma_f32<CONV3X3_RELU>),
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_conv_dma_f32<CONV3X3_RELU, NW>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e1 != hipSuccess) return e1;
         if (e2 != hipSuccess) return e2;
         attr_done = true;
     }
+    a2.dbg = nullptr;
+    const bool stamp = std::getenv("ADN_WINO_STAMP") != nullptr;      // diagnostic path only
+    const size_t dbg_bytes = (size_t)nwg * NW * 8 * sizeof(unsigned long long);
+    if (stamp) {
+        if (hipMalloc(&a2.dbg, dbg_bytes) != hipSuccess) return hipErrorOutOfMemory;
+        (void)hipMemsetAsync(a2.dbg, 0, dbg_bytes, st);
+    }
     if (kind == CONV3X3_RELU_POOL)
-        hipLaunchKernelGGL((wino_conv_dma_f32<CONV3X3_RELU_POOL>), dim3((unsigned)nwg), dim3(256), lds, st, a2);
+        hipLaunchKernelGGL((wino_conv_dma_f32<CONV3X3_RELU_POOL, NW>), dim3((unsigned)nwg), dim3(64 * NW), lds, st, a2);
     else
-        hipLaunchKernelGGL((wino_conv_dma_f32<CONV3X3_RELU>), dim3((unsigned)nwg), dim3(256), lds, st, a2);
-    return hipGetLastError();
+        hipLaunchKernelGGL((wino_conv_dma_f32<CONV3X3_RELU, NW>), dim3((unsigned)nwg), dim3(64 * NW), lds, st, a2);
+    hipError_t le = hipGetLastError();
+    if (stamp) {
+        std::vector<unsigned long long> hbuf(dbg_bytes / 8);
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(hbuf.data(), a2.dbg, dbg_bytes, hipMemcpyDeviceToHost);
+        (void)hipFree(a2.dbg);
+        double sum[6] = {0, 0, 0, 0, 0, 0};
+        double chunks = 0;
+        for (long b = 0; b < nwg * NW; ++b) {
+            for (int k = 0; k < 6; ++k) sum[k] += (double)hbuf[b * 8 + k];
+            chunks += (double)hbuf[b * 8 + 6];
+        }
+        if (chunks < 1) chunks = 1;
+        std::fprintf(stderr, "[wino stamp NW=%d] cycles per chunk per wave: dma_issue %.0f  patch_wait %.0f  transform %.0f  "
+                             "mfma %.0f  dma_wait %.0f  barrier %.0f\n", NW, sum[0] / chunks, sum[1] / chunks,
+                     sum[2] / chunks, sum[3] / chunks, sum[4] / chunks, sum[5] / chunks);
+    }
+    return le;
 }
 
 template <int NWN>
@@ -507,7 +640,10 @@ hipError_t launch_wino_n(ConvKind kind, const ConvArgs &a, hipStream_t st)
 // bn = output channels per workgroup (32 or 64); must match the packing done by adn_api.hip::pack_wino3x3
 hipError_t launch_wino_conv(ConvKind kind, const ConvArgs &a, int bn, bool dma, hipStream_t st)
 {
-    if (bn == 32 && dma) return launch_wino_dma(kind, a, st);
+    if (bn == 32 && dma) {
+        static const bool four = []() { const char *e = std::getenv("ADN_WINO_WAVES"); return e && std::atoi(e) == 4; }();
+        return four ? launch_wino_dma_n<4>(kind, a, st) : launch_wino_dma_n<8>(kind, a, st);
+    }
     return bn == 32 ? launch_wino_n<1>(kind, a, st) : launch_wino_n<2>(kind, a, st);
 }
 
