@@ -57,8 +57,7 @@ struct adn_unet {
     std::vector<hipEvent_t> events;
     int timing_max = 0, timing_count = 0;
     bool use_wino = true;          // 3x3 layers: Winograd F(2x2,3x3) kernel (false: direct implicit GEMM)
-    int wino_bn = 32;              // couts per Winograd workgroup (32: two 4-wave workgroups per CU; 64: one 8-wave)
-    bool wino_dma = true;          // stage through LDS-DMA (global_load_lds) instead of VGPRs
+    int wino_bn = 32;              // couts per Winograd workgroup
     size_t zeros_off = 0;          // 64 zero floats inside the packed buffer
 };
 
@@ -211,7 +210,7 @@ adn::ConvArgs conv_args(const adn_unet *h, const Conv3x3Layer &L, adn::ConvKind 
 
 hipError_t launch_conv3(const adn_unet *h, adn::ConvKind kind, const adn::ConvArgs &a, hipStream_t st)
 {
-    return h->use_wino ? adn::launch_wino_conv(kind, a, h->wino_bn, h->wino_dma, st) : adn::launch_conv_mfma(kind, a, st);
+    return h->use_wino ? adn::launch_wino_conv(kind, a, st) : adn::launch_conv_mfma(kind, a, st);
 }
 
 int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, void *workspace, size_t ws_bytes,
@@ -375,11 +374,8 @@ int adn_unet_create(adn_unet **handle, int device, const float *const *t, int n_
 
     adn_unet *h = new adn_unet();
     h->device = device;
-    if (const char *algo = std::getenv("ADN_CONV_ALGO")) {      // experiment switch: direct | wino32 | wino64
+    if (const char *algo = std::getenv("ADN_CONV_ALGO"))       // "direct": implicit-GEMM kernel instead of Winograd
         h->use_wino = std::strcmp(algo, "direct") != 0;
-        if (std::strcmp(algo, "wino64") == 0) h->wino_bn = 64;
-        if (std::strcmp(algo, "wino32r") == 0 || h->wino_bn == 64) h->wino_dma = false;   // register-staged variants
-    }
     std::vector<float> host;
     auto reserve = [&](size_t n) {
         const size_t at = host.size();

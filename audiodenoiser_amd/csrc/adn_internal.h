@@ -42,8 +42,8 @@ ConvGeom conv_geom(ConvKind kind, int Cout);
 size_t conv_packed_floats_per_chunk(ConvKind kind, int Cout);   // per (column tile, chunk)
 
 hipError_t launch_conv_mfma(ConvKind kind, const ConvArgs &a, hipStream_t st);
-// Winograd F(2x2,3x3) variant of the 3x3 kinds (wino_kernels.hip): tile 16x16 px x 64 couts, 8-channel chunks.
-hipError_t launch_wino_conv(ConvKind kind, const ConvArgs &a, int bn, bool dma, hipStream_t st);
+// Winograd F(2x2,3x3) variant of the 3x3 kinds (wino_kernels.hip): tile 16x16 px x 32 couts, 8-channel chunks.
+hipError_t launch_wino_conv(ConvKind kind, const ConvArgs &a, hipStream_t st);
 
 // First layer: Conv2d(1 -> 64, 3x3, pad 1) + folded BN + ReLU, NHWC output.  w9x64: [tap][cout].
 hipError_t launch_conv_first(const float *x, const float *w9x64, const float *bias, float *out,
