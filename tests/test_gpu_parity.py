@@ -97,6 +97,27 @@ def test_unet_full_size_batch64(net, dev, weights_np):
         assert _rel(y[i:i + 1].cpu().numpy(), ref) <= TOL
 
 
+@pytest.mark.parametrize("algo", ["direct", "winograd"])
+def test_unet_both_conv_algorithms(dev, weights_np, golden_dir, algo, monkeypatch):
+    """The 3x3 layers have two kernels: Winograd F(2x2,3x3) (default) and the direct implicit GEMM
+    (ADN_CONV_ALGO=direct, read when the handle is created).  Both must meet the same tolerance, on a shape with
+    pads in both dimensions and on the reference's own test shape."""
+    from audiodenoiser_amd.model import UNet
+    from audiodenoiser_amd.weights import make_input
+    if algo == "direct":
+        monkeypatch.setenv("ADN_CONV_ALGO", "direct")
+    else:
+        monkeypatch.delenv("ADN_CONV_ALGO", raising=False)
+    m = UNet(1, 1)
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in weights_np.items()}, strict=True)
+    m = m.to(dev).eval()
+    for (n, f, t) in ((2, 33, 47), (1, 257, 188)):
+        g = np.load(os.path.join(golden_dir, f"unet_{f}x{t}.npz"))
+        with torch.no_grad():
+            y = m(torch.from_numpy(make_input(7, n, f, t)).to(dev)).cpu().numpy()
+        assert _rel(y, g["y"]) <= TOL, (algo, f, t)
+
+
 def test_unet_weights_follow_state_dict_updates(dev, weights_np):
     """load_state_dict / in-place edits re-pack the weights (BatchNorm fold is redone)."""
     import oracle

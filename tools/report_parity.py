@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Print the measured parity of the HIP path against the committed reference goldens (run on the GPU box)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from audiodenoiser_amd.model import UNet  # noqa: E402
+from audiodenoiser_amd.weights import make_input, make_state_dict  # noqa: E402
+
+sd = make_state_dict(1234)
+net = UNet()
+net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+net = net.cuda().eval()
+algo = os.environ.get("ADN_CONV_ALGO", "winograd")
+for (n, f, t) in ((2, 16, 16), (2, 33, 47), (1, 64, 80), (1, 257, 188), (1, 513, 256)):
+    g = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", f"unet_{f}x{t}.npz"))
+    with torch.no_grad():
+        y = net(torch.from_numpy(make_input(7, n, f, t)).cuda()).cpu().numpy()
+    print(f"{algo:9s} {n}x1x{f}x{t}: max|y-ref|/max|ref| = {np.abs(y - g['y']).max() / np.abs(g['y']).max():.2e}")
