@@ -239,6 +239,7 @@ __global__ __launch_bounds__(STFT_THREADS) void stft_mag_kernel(const float *__r
 // through an LDS [bin][frame] image so that HBM stores run along the frame axis.
 // ------------------------------------------------------------------------------------------------
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ v2f vmul(v2f a, v2f b)   // complex multiply, packed-math friendly
 {
@@ -374,17 +375,31 @@ __global__ __launch_bounds__(NW * 64) void stft_wave_kernel(const float *__restr
     float *oclip = out + (long)clip * (M + 1) * n_frames;
     v2f *sc = s_sc + slot * SCSZ;
 
-    // ---- per-thread constants, loaded once per workgroup and kept in registers over all its frames ----
+    // ---- per-thread constants, kept in registers over all the workgroup's frames.  The 10 KB table is copied
+    // into LDS cooperatively (the [bin][frame] image is still unused) and each lane picks its 26 values from
+    // there: 10 KB of L2->CU traffic per workgroup instead of 53 KB of per-lane gathers (the kernel is bound by
+    // the CU's ingest path, not by HBM).
+    {
+        constexpr int TBL = N + 2 * M + (M + 2);
+        static_assert(TBL <= (M + 1) * MAGSTR, "table must fit the magnitude image");
+        for (int i = tid * 4; i < TBL; i += NT * 4) {
+            if (i + 4 <= TBL) *reinterpret_cast<f4 *>(s_mag + i) = *reinterpret_cast<const f4 *>(tables + i);
+            else
+                for (int j = i; j < TBL; ++j) s_mag[j] = tables[j];
+        }
+        __syncthreads();
+    }
     v2f win[8], tw2[(R2 - 1) * (8 / R2)], tw3[R3 > 1 ? (R3 - 1) * (8 / R3) : 1], twp[4];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) win[u] = *reinterpret_cast<const v2f *>(tables + 2 * (t + u * TPF));
-    load_pass_twiddles<M, R2, 8>(tables, t, tw2);
-    if constexpr (R3 > 1) load_pass_twiddles<M, R3, 8 * R2>(tables, t, tw3);
+    for (int u = 0; u < 8; ++u) win[u] = *reinterpret_cast<const v2f *>(s_mag + 2 * (t + u * TPF));
+    load_pass_twiddles<M, R2, 8>(s_mag, t, tw2);
+    if constexpr (R3 > 1) load_pass_twiddles<M, R3, 8 * R2>(s_mag, t, tw3);
     {
-        const v2f *g2 = reinterpret_cast<const v2f *>(tables + N + 2 * M);
+        const v2f *g2 = reinterpret_cast<const v2f *>(s_mag + N + 2 * M);
 #pragma unroll
         for (int b = 0; b < 4; ++b) twp[b] = g2[t + b * TPF];
     }
+    __syncthreads();                                      // everyone holds its constants: the image may be written
 
     const int Li = (int)L;                                // adn_stft_mag guarantees L < 2^30
     const bool base_aligned = (reinterpret_cast<uintptr_t>(aud) & 7) == 0;
@@ -423,7 +438,22 @@ __global__ __launch_bounds__(NW * 64) void stft_wave_kernel(const float *__restr
         // software prefetch: the next frame's loads fly under this frame's FFT
         int gn = g, fn = fi + 1;
         if (fn == FPS) { fn = 0; ++gn; }
-        if (it + 1 < n_seq) load_frame(gn * FPB + slot * FPS + fn, nx);
+        if (it + 1 < n_seq) {
+            const int fnx = gn * FPB + slot * FPS + fn;
+            const int fs = fnx * hop - pad;
+            // hop = n_fft/4 (the reference's and BASELINE's setting): the next frame of this slot starts 2*TPF
+            // complex points later, i.e. its element u is this frame's element u+2 -> shift six registers and load
+            // two (each audio sample is read once instead of four times)
+            if (hop * 4 == N && fn != 0 && fs >= 0 && fs + N <= Li && base_aligned && !(fs & 1) && !(ablate & 1)) {
+#pragma unroll
+                for (int u = 0; u < 6; ++u) nx[u] = nx[u + 2];
+                const float *ap = aud + fs + 2 * t;
+                nx[6] = *reinterpret_cast<const v2f *>(ap + 2 * 6 * TPF);
+                nx[7] = *reinterpret_cast<const v2f *>(ap + 2 * 7 * TPF);
+            } else {
+                load_frame(fnx, nx);
+            }
+        }
 
         // pass 1: radix 8, P = 1
         vdft<8>(v);
