@@ -51,9 +51,12 @@ def load() -> ctypes.CDLL:
         L.adn_stft_mag.argtypes = [vp, ci, cl, ci, ci, ci, vp, vp]
         L.adn_quantize_pad.argtypes = [vp, ci, ci, ci, vp, ci, ci, vp]
         L.adn_per_clip_l1.argtypes = [vp, vp, ci, cl, vp, vp]
+        L.adn_perceptual_loss_workspace_bytes.argtypes = [ci, ci, ci, ctypes.POINTER(sz)]
+        L.adn_perceptual_loss.argtypes = [vp, vp, ci, ci, ci, vp, sz, vp, vp]
         for name in ("adn_device_count", "adn_unet_create", "adn_unet_destroy", "adn_unet_workspace_bytes",
                      "adn_unet_forward", "adn_unet_forward_taps", "adn_unet_set_timing", "adn_unet_get_timing",
-                     "adn_stft_n_frames", "adn_stft_mag", "adn_quantize_pad", "adn_per_clip_l1"):
+                     "adn_stft_n_frames", "adn_stft_mag", "adn_quantize_pad", "adn_per_clip_l1",
+                     "adn_perceptual_loss_workspace_bytes", "adn_perceptual_loss"):
             getattr(L, name).restype = ci
         _lib = L
         return L
@@ -69,5 +72,5 @@ EXPORTED_SYMBOLS = (
     "adn_version", "adn_last_error", "adn_device_count", "adn_unet_create", "adn_unet_destroy",
     "adn_unet_workspace_bytes", "adn_unet_forward", "adn_unet_forward_taps", "adn_unet_set_timing",
     "adn_unet_get_timing", "adn_stft_n_frames", "adn_stft_mag",
-    "adn_quantize_pad", "adn_per_clip_l1",
+    "adn_quantize_pad", "adn_per_clip_l1", "adn_perceptual_loss_workspace_bytes", "adn_perceptual_loss",
 )

@@ -556,4 +556,23 @@ int adn_per_clip_l1(const float *a, const float *b, int n_clips, long elems_per_
     return ADN_OK;
 }
 
+int adn_perceptual_loss_workspace_bytes(int n_clips, int F, int T, size_t *bytes)
+{
+    if (!bytes || n_clips < 1 || F < 1 || T < 64) return fail(ADN_ERR_INVALID, "adn_perceptual_loss_workspace_bytes: need n_clips,F >= 1 and T >= 64");
+    *bytes = adn::perceptual_loss_workspace_floats(n_clips, F, T) * sizeof(float);
+    return ADN_OK;
+}
+
+int adn_perceptual_loss(const float *pred, const float *target, int n_clips, int F, int T, void *workspace,
+                        size_t workspace_bytes, float *out, void *stream)
+{
+    if (!pred || !target || !out) return fail(ADN_ERR_INVALID, "adn_perceptual_loss: null pointer");
+    if (n_clips < 1 || F < 1 || T < 64 || T > 6000) return fail(ADN_ERR_INVALID, "adn_perceptual_loss: need n_clips,F >= 1 and 64 <= T <= 6000");
+    const size_t need = adn::perceptual_loss_workspace_floats(n_clips, F, T) * sizeof(float);
+    if (!workspace || workspace_bytes < need) return fail(ADN_ERR_WORKSPACE, "adn_perceptual_loss: workspace too small");
+    ADN_HIP(adn::launch_perceptual_loss(pred, target, n_clips, F, T, static_cast<float *>(workspace), out,
+                                        static_cast<hipStream_t>(stream)));
+    return ADN_OK;
+}
+
 }  // extern "C"

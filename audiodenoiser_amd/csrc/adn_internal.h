@@ -57,5 +57,8 @@ hipError_t launch_stft_mag(const float *audio, int n_clips, long L, int n_fft, i
                            long n_frames, float *out, hipStream_t st);
 hipError_t launch_quantize_pad(const float *in, int n, int h, int w, float *out, int H, int W, hipStream_t st);
 hipError_t launch_per_clip_l1(const float *a, const float *b, int n_clips, long elems, float *out, hipStream_t st);
+size_t perceptual_loss_workspace_floats(int n_clips, int F, int T);
+hipError_t launch_perceptual_loss(const float *pred, const float *tgt, int n_clips, int F, int T, float *workspace,
+                                  float *out, hipStream_t st);
 
 }  // namespace adn

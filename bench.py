@@ -6,8 +6,8 @@
         bench.py --gpus N --steps K --warmup W
 
 A step = one forward of the hot path over one resident batch per GPU (BASELINE configs[1]: batch 64 of
-synthetic 513x256 fp32 spectrograms) + the per-clip L1 kernel, and for N > 1 the one RCCL all-gather of the
-per-clip values (clips shard over ranks, weights replicated, no data-path collective; weak scaling: the batch
+synthetic 513x256 fp32 spectrograms) + the per-clip CombinedPerceptualLoss kernels, and for N > 1 the one RCCL
+all-gather of the per-clip values (4 floats per clip) (clips shard over ranks, weights replicated, no data-path collective; weak scaling: the batch
 per GPU is fixed).  Rank 0 prints ONE JSON line; `value` = all ranks' frames / max-over-ranks time.
 
 roofline: the dominant kernel is wino_conv_dma_f32 (the 17 3x3 convolutions, 95 % of the FLOPs; Winograd
@@ -106,7 +106,7 @@ def main() -> None:
 
     from audiodenoiser_amd import _lib
     from audiodenoiser_amd import distributed as D
-    from audiodenoiser_amd.loss import per_clip_l1
+    from audiodenoiser_amd.loss import perceptual_loss_per_clip
     from audiodenoiser_amd.model import UNet
     from audiodenoiser_amd.roofline import PEAK_HBM_GBS, PEAK_MFMA_F32_TFLOPS, unet_launches
     from audiodenoiser_amd.weights import make_state_dict
@@ -131,8 +131,8 @@ def main() -> None:
 
     def step():
         y = net(x)
-        loss = per_clip_l1(y, target)
-        return D.gather_per_clip(loss)
+        loss = perceptual_loss_per_clip(y, target)            # (b, 4): total, stft, mel, l1 per clip
+        return D.gather_per_clip(loss.reshape(-1))
 
     with torch.no_grad():
         for _ in range(args.warmup):
@@ -148,7 +148,7 @@ def main() -> None:
         D.barrier()
         elapsed = time.perf_counter() - t0
     elapsed = D.max_over_ranks(elapsed, dev)
-    assert allv.numel() == b * world and bool(torch.isfinite(allv).all())
+    assert allv.numel() == 4 * b * world and bool(torch.isfinite(allv).all())
 
     # per-launch durations of the timed steps (events recorded on the launch stream inside libadn)
     ms = np.zeros((args.steps, 23), dtype=np.float32)
@@ -189,7 +189,7 @@ def main() -> None:
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"batch={b} per GPU synthetic 513x256 fp32 spectrograms, full U-Net forward "
-                                   "(BASELINE configs[1]) + per-clip L1" + (" + all-gather" if world > 1 else ""),
+                                   "(BASELINE configs[1]) + per-clip perceptual loss" + (" + all-gather" if world > 1 else ""),
                        "batch_per_gpu": b, "global_batch": b * world, "freq_bins": F_BINS, "frames": T_FRAMES,
                        "parallelism": f"clips sharded over {world} rank(s), weights replicated"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_MFMA_F32_TFLOPS,

@@ -97,6 +97,15 @@ int adn_quantize_pad(const float *in, int n, int h, int w, float *out, int H, in
  * code/loss.py:86):  out[i] = mean_j |a[i,j] - b[i,j]|. */
 int adn_per_clip_l1(const float *a, const float *b, int n_clips, long elems_per_clip, float *out, void *stream);
 
+/* Per-clip CombinedPerceptualLoss: replaces, clip by clip, CombinedPerceptualLoss.forward and the two losses it
+ * calls (code/loss.py:6-95; caller code/test.py:118-122).  pred, target: (n_clips,1,F,T) fp32 device tensors;
+ * out: (n_clips,4) = {total, stft, mel, l1}.  The reference's batch values are the means over clips (equal clip
+ * sizes).  Constants are the reference's: scales (63,16),(32,8),(16,4); mel: sr 8000, n_fft 63, hop 16, 64 mels;
+ * weights 0.4/0.4/0.2.  Needs T >= 64 and adn_perceptual_loss_workspace_bytes of device scratch. */
+int adn_perceptual_loss_workspace_bytes(int n_clips, int F, int T, size_t *bytes);
+int adn_perceptual_loss(const float *pred, const float *target, int n_clips, int F, int T, void *workspace,
+                        size_t workspace_bytes, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -157,6 +157,27 @@ def test_c_abi_error_paths(net, dev):
         net(torch.zeros(1, 2, 16, 16, device=dev))
 
 
+def test_config0_wav_to_spectrogram_to_forward(net, dev, weights_np):
+    """BASELINE configs[0] end to end on the device: one 3 s @ 44.1 kHz clip -> STFT 1024/256 centred (513x517)
+    -> loader rule (fp16 round trip, crop to 513x256) -> forward, batch 1.  (The reference's own clips are not
+    shipped; a synthetic clip of the same shape stands in)  Each stage is checked against the
+    oracle on the SAME input the next stage consumes, so fp16 rounding ties cannot leak between stages."""
+    import oracle
+    from oracle import unet_torch
+    from audiodenoiser_amd.data_loader import quantize_pad_on_device
+    from audiodenoiser_amd.stft import stft_magnitude
+    clip = np.random.default_rng(0).uniform(-1, 1, 132300).astype(np.float32)
+    mag = stft_magnitude(torch.from_numpy(clip).to(dev), 1024, 256, True)
+    assert tuple(mag.shape) == (513, 517)
+    assert _rel(mag.cpu().numpy(), oracle.stft_mag(clip, 1024, 256, True)) <= TOL
+    x = quantize_pad_on_device(mag[None], (513, 256))
+    assert np.array_equal(x.cpu().numpy()[0, 0], oracle.quantize_pad(mag.cpu().numpy(), (513, 256)))
+    with torch.no_grad():
+        y = net(x)
+    ref = unet_torch.unet_forward(unet_torch.to_torch_state(weights_np), x.cpu()).numpy()
+    assert y.shape == (1, 1, 513, 256) and _rel(y.cpu().numpy(), ref) <= TOL
+
+
 # ---------------------------------------------------------------------------------------------- STFT
 STFT_CASES = [(16000, 512, 128, False), (24000, 512, 128, True), (132300, 1024, 256, True),
               (132300, 1024, 256, False), (5000, 2048, 512, True), (4096, 4096, 1024, False),
@@ -271,3 +292,33 @@ def test_per_clip_l1(dev):
     got = per_clip_l1(a.to(dev), b.to(dev)).cpu().numpy()
     ref = (a.double() - b.double()).abs().reshape(5, -1).mean(dim=1).numpy()
     assert np.allclose(got, ref, rtol=1e-5)
+
+
+@pytest.mark.parametrize("b,f,t", [(3, 40, 96), (2, 257, 188), (4, 513, 256), (1, 33, 64)])
+def test_perceptual_loss_per_clip(dev, b, f, t):
+    """Per-clip CombinedPerceptualLoss (loss.py:6-95) against the torch oracle; tolerance 1e-4 relative per term.
+    (Mel term: parity unpinned upstream, torchaudio absent — oracle restates its published defaults.)"""
+    from oracle import loss_torch
+    from audiodenoiser_amd.loss import CombinedPerceptualLoss, perceptual_loss_per_clip
+    g = torch.Generator().manual_seed(5)
+    pred = torch.rand((b, 1, f, t), generator=g) * 3
+    tgt = torch.rand((b, 1, f, t), generator=g) * 3
+    ref = loss_torch.per_clip(pred, tgt).numpy()
+    got = perceptual_loss_per_clip(pred.to(dev), tgt.to(dev)).cpu().numpy()
+    assert got.shape == (b, 4)
+    assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max(), (got, ref)
+    assert np.allclose(got, ref, rtol=2e-4, atol=1e-6)
+    total, stft, mel, l1 = CombinedPerceptualLoss()(pred.to(dev), tgt.to(dev))
+    assert abs(float(l1) - float(torch.nn.functional.l1_loss(pred, tgt))) < 1e-5
+    assert abs(float(total) - float(ref[:, 0].mean())) < 1e-4 * float(ref[:, 0].mean())
+
+
+def test_perceptual_loss_zero_and_errors(dev):
+    from audiodenoiser_amd.loss import perceptual_loss_per_clip
+    x = torch.rand((2, 1, 64, 128), device=dev)
+    assert float(perceptual_loss_per_clip(x, x.clone()).abs().max()) == 0.0
+    with pytest.raises(ValueError):
+        perceptual_loss_per_clip(x, x[:, :, :32])
+    from audiodenoiser_amd._lib import AdnError
+    with pytest.raises(AdnError):
+        perceptual_loss_per_clip(x[..., :32].contiguous(), x[..., :32].contiguous())     # T < 64
