@@ -56,7 +56,8 @@ struct adn_unet {
     // optional per-launch timing (adn_unet_set_timing)
     std::vector<hipEvent_t> events;
     int timing_max = 0, timing_count = 0;
-    bool use_wino = true;          // 3x3 layers: Winograd F(2x2,3x3) kernel (false: direct implicit GEMM)
+    bool f16 = false;              // fp16 storage + fp16 MFMA (fp32 accumulate); x and y stay fp32 at the ABI
+    bool use_wino = true;          // fp32 3x3 layers: Winograd F(2x2,3x3) kernel (false: direct implicit GEMM)
     int wino_bn = 32;              // couts per Winograd workgroup
     size_t zeros_off = 0;          // 64 zero floats inside the packed buffer
 };
@@ -77,12 +78,15 @@ void bn_fold(const float *b, const float *gamma, const float *beta, const float 
     }
 }
 
-// Packed layout consumed by conv_mfma_f32 (conv_kernels.hip): [column tile][chunk][tap][kgroup][half][n][4]
-// where element kk of (kgroup s, half h) is input channel chunk*KC + 8*s + 4*h + kk.
-void pack_conv3x3(const float *w /*(Cout,Cin,3,3)*/, const std::vector<float> &scale, int Cin, int Cout, float *dst)
+// Packed layout consumed by conv_mfma<T> (conv_kernels.hip): [column tile][chunk][tap][kgroup][half][n][EPV]
+// where EPV = elements per 16 bytes (4 floats / 8 halfs) and element kk of (kgroup s, half h) is input channel
+// chunk*KC + 2*EPV*s + EPV*h + kk.
+template <typename T>
+void pack_conv3x3(const float *w /*(Cout,Cin,3,3)*/, const std::vector<float> &scale, int Cin, int Cout, T *dst)
 {
-    const adn::ConvGeom g = adn::conv_geom(adn::CONV3X3_RELU, Cout);
-    const int BN = g.BN, KC = g.KC, KG = KC / 8;
+    constexpr int EPV = 16 / sizeof(T);
+    const adn::ConvGeom g = adn::conv_geom(adn::CONV3X3_RELU, Cout, sizeof(T) == 2);
+    const int BN = g.BN, KC = g.KC, KG = KC / (2 * EPV);
     const int nct = Cout / BN, nchunk = Cin / KC;
     size_t o = 0;
     for (int ct = 0; ct < nct; ++ct)
@@ -92,9 +96,9 @@ void pack_conv3x3(const float *w /*(Cout,Cin,3,3)*/, const std::vector<float> &s
                     for (int h = 0; h < 2; ++h)
                         for (int n = 0; n < BN; ++n) {
                             const int co = ct * BN + n;
-                            for (int kk = 0; kk < 4; ++kk) {
-                                const int ci = ch * KC + 8 * s + 4 * h + kk;
-                                dst[o++] = w[((size_t)co * Cin + ci) * 9 + tap] * scale[co];
+                            for (int kk = 0; kk < EPV; ++kk) {
+                                const int ci = ch * KC + 2 * EPV * s + EPV * h + kk;
+                                dst[o++] = (T)(w[((size_t)co * Cin + ci) * 9 + tap] * scale[co]);
                             }
                         }
 }
@@ -124,10 +128,12 @@ void pack_wino3x3(const float *w /*(Cout,Cin,3,3)*/, const std::vector<float> &s
 }
 
 // ConvTranspose2d(k2,s2) as a GEMM with columns col = (i*2+j)*Cout + co, K = Cin.
-void pack_convt(const float *w /*(Cin,Cout,2,2)*/, int Cin, int Cout, float *dst)
+template <typename T>
+void pack_convt(const float *w /*(Cin,Cout,2,2)*/, int Cin, int Cout, T *dst)
 {
-    const adn::ConvGeom g = adn::conv_geom(adn::CONVT2X2, Cout);
-    const int BN = g.BN, KC = g.KC, KG = KC / 8;
+    constexpr int EPV = 16 / sizeof(T);
+    const adn::ConvGeom g = adn::conv_geom(adn::CONVT2X2, Cout, sizeof(T) == 2);
+    const int BN = g.BN, KC = g.KC, KG = KC / (2 * EPV);
     const int ncol = 4 * Cout, nct = ncol / BN, nchunk = Cin / KC;
     size_t o = 0;
     for (int ct = 0; ct < nct; ++ct)
@@ -137,19 +143,19 @@ void pack_convt(const float *w /*(Cin,Cout,2,2)*/, int Cin, int Cout, float *dst
                     for (int n = 0; n < BN; ++n) {
                         const int col = ct * BN + n;
                         const int ij = col / Cout, co = col % Cout;
-                        for (int kk = 0; kk < 4; ++kk) {
-                            const int ci = ch * KC + 8 * s + 4 * h + kk;
-                            dst[o++] = w[((size_t)ci * Cout + co) * 4 + ij];
+                        for (int kk = 0; kk < EPV; ++kk) {
+                            const int ci = ch * KC + 2 * EPV * s + EPV * h + kk;
+                            dst[o++] = (T)w[((size_t)ci * Cout + co) * 4 + ij];
                         }
                     }
 }
 
 struct Plan {
     int N, H[5], W[5];
-    size_t tA, tB, skip[4], pool[4], total;   // float offsets
+    size_t tA, tB, skip[4], pool[4], total;   // BYTE offsets into the workspace
 };
 
-bool make_plan(int N, int F, int T, Plan &p)
+bool make_plan(int N, int F, int T, bool f16, Plan &p)
 {
     if (N < 1 || F < 16 || T < 16) return false;
     p.N = N;
@@ -159,10 +165,11 @@ bool make_plan(int N, int F, int T, Plan &p)
         p.H[l] = p.H[l - 1] / 2;
         p.W[l] = p.W[l - 1] / 2;
     }
+    const size_t es = f16 ? 2 : 4;
     size_t o = 0;
     auto take = [&](size_t n) {
         const size_t at = o;
-        o += (n + 63) & ~size_t(63);   // 256-byte granules
+        o += (n * es + 255) & ~size_t(255);   // 256-byte granules
         return at;
     };
     const size_t full = (size_t)N * p.H[0] * p.W[0] * 64;
@@ -176,11 +183,11 @@ bool make_plan(int N, int F, int T, Plan &p)
     return true;
 }
 
-adn::ConvArgs conv_args(const adn_unet *h, const Conv3x3Layer &L, adn::ConvKind kind, const float *in0, int C0,
-                        const float *in1, int C1, int H1, int W1, float *out, float *pool, int N, int H, int W)
+adn::ConvArgs conv_args(const adn_unet *h, const Conv3x3Layer &L, adn::ConvKind kind, const void *in0, int C0,
+                        const void *in1, int C1, int H1, int W1, void *out, void *pool, int N, int H, int W)
 {
-    adn::ConvGeom g = adn::conv_geom(kind, L.Cout);
-    if (h->use_wino) g = adn::ConvGeom{16, h->wino_bn, 8};   // wino_conv_f32 tile: 16x16 px x wino_bn couts, 8-ch chunks
+    adn::ConvGeom g = adn::conv_geom(kind, L.Cout, h->f16);
+    if (h->use_wino) g = adn::ConvGeom{16, h->wino_bn, 8};   // wino_conv_dma_f32 tile: 16x16 px x wino_bn couts, 8-ch chunks
     adn::ConvArgs a;
     a.s0 = adn::ConvSrc{in0, H, W, C0, 0, 0};
     if (in1) {
@@ -210,7 +217,7 @@ adn::ConvArgs conv_args(const adn_unet *h, const Conv3x3Layer &L, adn::ConvKind 
 
 hipError_t launch_conv3(const adn_unet *h, adn::ConvKind kind, const adn::ConvArgs &a, hipStream_t st)
 {
-    return h->use_wino ? adn::launch_wino_conv(kind, a, st) : adn::launch_conv_mfma(kind, a, st);
+    return h->use_wino ? adn::launch_wino_conv(kind, a, st) : adn::launch_conv_mfma(kind, a, h->f16, st);
 }
 
 int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, void *workspace, size_t ws_bytes,
@@ -218,15 +225,16 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
 {
     if (!h || !x || !y) return fail(ADN_ERR_INVALID, "adn_unet_forward: null handle/x/y");
     Plan p;
-    if (!make_plan(N, F, T, p)) return fail(ADN_ERR_INVALID, "adn_unet_forward: need N>=1 and F,T>=16");
-    if (!workspace || ws_bytes < p.total * sizeof(float))
+    if (!make_plan(N, F, T, h->f16, p)) return fail(ADN_ERR_INVALID, "adn_unet_forward: need N>=1 and F,T>=16");
+    if (!workspace || ws_bytes < p.total)
         return fail(ADN_ERR_WORKSPACE, "adn_unet_forward: workspace too small (see adn_unet_workspace_bytes)");
     int cur_dev = -1;
     ADN_HIP(hipGetDevice(&cur_dev));
     if (cur_dev != h->device) ADN_HIP(hipSetDevice(h->device));
 
-    float *ws = static_cast<float *>(workspace);
-    float *tA = ws + p.tA, *tB = ws + p.tB;
+    char *ws = static_cast<char *>(workspace);      // activations are fp32 or fp16 (h->f16); offsets are bytes
+    void *tA = ws + p.tA, *tB = ws + p.tB;
+    const bool f16 = h->f16;
     // timing hook: events[slot*(L+1) + k] is recorded before launch k (k = L: after the last one)
     const bool timed = h->timing_max > 0 && h->timing_count < h->timing_max && !taps;
     hipEvent_t *ev = timed ? h->events.data() + (size_t)h->timing_count * (ADN_N_LAUNCHES + 1) : nullptr;
@@ -236,18 +244,18 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
         if (timed) ADN_HIP(hipEventRecord(ev[evi++], st));  \
     } while (0)
 
-    auto export_tap = [&](int idx, const float *nhwc, int C, int Hh, int Ww) -> hipError_t {
+    auto export_tap = [&](int idx, const void *nhwc, int C, int Hh, int Ww) -> hipError_t {
         if (!taps || !taps[idx]) return hipSuccess;
-        return adn::launch_nhwc_to_nchw(nhwc, taps[idx], N, Hh, Ww, C, st);
+        return adn::launch_nhwc_to_nchw(nhwc, f16, taps[idx], N, Hh, Ww, C, st);
     };
 
     // ---- down path (model.py:72-79) ----
     ADN_MARK();
-    ADN_HIP(adn::launch_conv_first(x, h->dev + h->first_w, h->dev + h->first_b, tA, N, p.H[0], p.W[0], st));
+    ADN_HIP(adn::launch_conv_first(x, h->dev + h->first_w, h->dev + h->first_b, tA, f16, N, p.H[0], p.W[0], st));
     int li = 0;
-    const float *cur = tA;
+    const void *cur = tA;
     for (int l = 0; l < 4; ++l) {
-        float *skip = ws + p.skip[l], *pool = ws + p.pool[l];
+        void *skip = ws + p.skip[l], *pool = ws + p.pool[l];
         if (l > 0) {
             adn::ConvArgs a = conv_args(h, h->c3[li], adn::CONV3X3_RELU, ws + p.pool[l - 1], CH[l - 1], nullptr, 0, 0, 0,
                                         tA, nullptr, N, p.H[l], p.W[l]);
@@ -278,12 +286,12 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
         ADN_HIP(export_tap(4, tB, 1024, p.H[4], p.W[4]));
     }
     // ---- up path (model.py:84-91): convT -> (virtual) pad + cat([skip, up]) -> DoubleConv ----
-    float *X = tB, *Y = tA;   // X holds the current tensor
+    void *X = tB, *Y = tA;   // X holds the current tensor
     int uh = p.H[4], uw = p.W[4], upc = 1024;
     for (int l = 3; l >= 0; --l) {
         const int co = CH[l];
         const ConvTLayer &TL = h->ct[3 - l];
-        const adn::ConvGeom g = adn::conv_geom(adn::CONVT2X2, co);
+        const adn::ConvGeom g = adn::conv_geom(adn::CONVT2X2, co, f16);
         adn::ConvArgs t;
         t.s0 = adn::ConvSrc{X, uh, uw, upc, 0, 0};
         t.s1 = adn::ConvSrc{X, 0, 0, 0, 0, 0};
@@ -303,7 +311,7 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
         t.zeros = h->dev + h->zeros_off;
         t.dbg = nullptr;
         ADN_MARK();
-        ADN_HIP(adn::launch_conv_mfma(adn::CONVT2X2, t, st));
+        ADN_HIP(adn::launch_conv_mfma(adn::CONVT2X2, t, f16, st));
         // first conv of the DoubleConv reads cat([skip, x1]) virtually
         adn::ConvArgs a = conv_args(h, h->c3[li], adn::CONV3X3_RELU, ws + p.skip[l], co, Y, co, 2 * uh, 2 * uw, X, nullptr,
                                     N, p.H[l], p.W[l]);
@@ -315,7 +323,7 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
         ADN_HIP(launch_conv3(h, adn::CONV3X3_RELU, b, st));
         ++li;
         ADN_HIP(export_tap(5 + (3 - l), Y, co, p.H[l], p.W[l]));
-        float *tmp = X;
+        void *tmp = X;
         X = Y;
         Y = tmp;
         uh = p.H[l];
@@ -324,7 +332,7 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
     }
     // ---- 1x1 output convolution (model.py:93) ----
     ADN_MARK();
-    ADN_HIP(adn::launch_conv_out(X, h->dev + h->out_w, h->out_b, y, (long)N * F * T, st));
+    ADN_HIP(adn::launch_conv_out(X, f16, h->dev + h->out_w, h->out_b, y, (long)N * F * T, st));
     ADN_MARK();
     if (timed) {
         if (evi != ADN_N_LAUNCHES + 1) return fail(ADN_ERR_INVALID, "internal: launch count mismatch");
@@ -359,7 +367,13 @@ int adn_device_count(int *count)
 
 int adn_unet_create(adn_unet **handle, int device, const float *const *t, int n_tensors)
 {
+    return adn_unet_create_ex(handle, device, t, n_tensors, ADN_DTYPE_F32);
+}
+
+int adn_unet_create_ex(adn_unet **handle, int device, const float *const *t, int n_tensors, int dtype)
+{
     if (!handle || !t) return fail(ADN_ERR_INVALID, "adn_unet_create: null argument");
+    if (dtype != ADN_DTYPE_F32 && dtype != ADN_DTYPE_F16) return fail(ADN_ERR_INVALID, "adn_unet_create: dtype must be ADN_DTYPE_F32 or ADN_DTYPE_F16");
     if (n_tensors != ADN_N_WEIGHT_TENSORS) return fail(ADN_ERR_INVALID, "adn_unet_create: expected 118 tensors");
     for (int i = 0; i < n_tensors; ++i)
         if (!t[i]) return fail(ADN_ERR_INVALID, "adn_unet_create: null tensor pointer");
@@ -374,8 +388,10 @@ int adn_unet_create(adn_unet **handle, int device, const float *const *t, int n_
 
     adn_unet *h = new adn_unet();
     h->device = device;
+    h->f16 = dtype == ADN_DTYPE_F16;
     if (const char *algo = std::getenv("ADN_CONV_ALGO"))       // "direct": implicit-GEMM kernel instead of Winograd
         h->use_wino = std::strcmp(algo, "direct") != 0;
+    if (h->f16) h->use_wino = false;                           // the fp16 path runs the direct fp16-MFMA kernels
     std::vector<float> host;
     auto reserve = [&](size_t n) {
         const size_t at = host.size();
@@ -395,9 +411,12 @@ int adn_unet_create(adn_unet **handle, int device, const float *const *t, int n_
         if (h->use_wino) {
             L.w_off = reserve((size_t)16 * Cin * Cout);
             pack_wino3x3(t[ti], scale, Cin, Cout, h->wino_bn, host.data() + L.w_off);
+        } else if (h->f16) {
+            L.w_off = reserve(((size_t)9 * Cin * Cout + 1) / 2);
+            pack_conv3x3<_Float16>(t[ti], scale, Cin, Cout, reinterpret_cast<_Float16 *>(host.data() + L.w_off));
         } else {
             L.w_off = reserve((size_t)9 * Cin * Cout);
-            pack_conv3x3(t[ti], scale, Cin, Cout, host.data() + L.w_off);
+            pack_conv3x3<float>(t[ti], scale, Cin, Cout, host.data() + L.w_off);
         }
         L.b_off = reserve(Cout);
         std::memcpy(host.data() + L.b_off, bias.data(), sizeof(float) * Cout);
@@ -425,8 +444,13 @@ int adn_unet_create(adn_unet **handle, int device, const float *const *t, int n_
         ConvTLayer &TL = h->ct[3 - l];
         TL.Cin = cin;
         TL.Cout = co;
-        TL.w_off = reserve((size_t)4 * cin * co);
-        pack_convt(t[ti], cin, co, host.data() + TL.w_off);
+        if (h->f16) {
+            TL.w_off = reserve(((size_t)4 * cin * co + 1) / 2);
+            pack_convt<_Float16>(t[ti], cin, co, reinterpret_cast<_Float16 *>(host.data() + TL.w_off));
+        } else {
+            TL.w_off = reserve((size_t)4 * cin * co);
+            pack_convt<float>(t[ti], cin, co, host.data() + TL.w_off);
+        }
         TL.b_off = reserve((size_t)4 * co);
         for (int ij = 0; ij < 4; ++ij)
             for (int c = 0; c < co; ++c) host[TL.b_off + (size_t)ij * co + c] = t[ti + 1][c];
@@ -496,11 +520,10 @@ int adn_unet_destroy(adn_unet *h)
 
 int adn_unet_workspace_bytes(const adn_unet *h, int N, int F, int T, size_t *bytes)
 {
-    (void)h;
     if (!bytes) return fail(ADN_ERR_INVALID, "adn_unet_workspace_bytes: null");
     Plan p;
-    if (!make_plan(N, F, T, p)) return fail(ADN_ERR_INVALID, "adn_unet_workspace_bytes: need N>=1 and F,T>=16");
-    *bytes = p.total * sizeof(float);
+    if (!make_plan(N, F, T, h ? h->f16 : false, p)) return fail(ADN_ERR_INVALID, "adn_unet_workspace_bytes: need N>=1 and F,T>=16");
+    *bytes = p.total;
     return ADN_OK;
 }
 

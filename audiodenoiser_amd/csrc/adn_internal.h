@@ -6,22 +6,23 @@
 
 namespace adn {
 
-// One NHWC fp32 activation source of a convolution.  (offY, offX) is the zero-pad placed above / left of
-// the tensor when it is aligned to the output domain (UpSampleLayer's F.pad, reference model.py:44-47).
+// One NHWC activation source of a convolution (fp32 or fp16 storage, decided by the launcher).  (offY, offX) is
+// the zero-pad placed above / left of the tensor when it is aligned to the output domain (UpSampleLayer's F.pad,
+// reference model.py:44-47).
 struct ConvSrc {
-    const float *ptr;
+    const void *ptr;
     int H, W, C;
     int offY, offX;
 };
 
-// Arguments of the MFMA implicit-GEMM kernel (3x3 convolution or 2x2-stride-2 transposed convolution).
+// Arguments of the matrix-core convolution kernels (3x3 convolution or 2x2-stride-2 transposed convolution).
 struct ConvArgs {
     ConvSrc s0, s1;        // channels [0, s0.C) come from s0, [s0.C, s0.C + s1.C) from s1 (virtual concat)
     int nchunk0, nchunk;   // K-chunks served by s0 / in total
-    const float *wpk;      // packed weights, see pack_conv3x3 / pack_convt in adn_api.hip
-    const float *bias;     // per GEMM column (BatchNorm folded)
-    float *out;            // NHWC output
-    float *pool;           // optional 2x2 max-pooled NHWC output (EPI_RELU_POOL)
+    const void *wpk;       // packed weights, see pack_* in adn_api.hip
+    const float *bias;     // per GEMM column (BatchNorm folded), always fp32
+    void *out;             // NHWC output
+    void *pool;            // optional 2x2 max-pooled NHWC output (CONV3X3_RELU_POOL)
     int N, H, W;           // tile domain: output H,W for 3x3; INPUT h,w for the transposed convolution
     int Cout;              // output channels of the layer (GEMM columns = Cout, or 4*Cout for convT)
     int tilesY, tilesX, nct;
@@ -38,20 +39,20 @@ struct ConvGeom {
     int BN;      // GEMM columns per block
     int KC;      // channels per K-chunk
 };
-ConvGeom conv_geom(ConvKind kind, int Cout);
-size_t conv_packed_floats_per_chunk(ConvKind kind, int Cout);   // per (column tile, chunk)
+ConvGeom conv_geom(ConvKind kind, int Cout, bool f16);
 
-hipError_t launch_conv_mfma(ConvKind kind, const ConvArgs &a, hipStream_t st);
-// Winograd F(2x2,3x3) variant of the 3x3 kinds (wino_kernels.hip): tile 16x16 px x 32 couts, 8-channel chunks.
+// Direct implicit-GEMM kernels (conv_kernels.hip), fp32 or fp16 storage.
+hipError_t launch_conv_mfma(ConvKind kind, const ConvArgs &a, bool f16, hipStream_t st);
+// Winograd F(2x2,3x3) variant of the 3x3 kinds, fp32 only (wino_kernels.hip): tile 16x16 px x 32 couts, 8-ch chunks.
 hipError_t launch_wino_conv(ConvKind kind, const ConvArgs &a, hipStream_t st);
 
-// First layer: Conv2d(1 -> 64, 3x3, pad 1) + folded BN + ReLU, NHWC output.  w9x64: [tap][cout].
-hipError_t launch_conv_first(const float *x, const float *w9x64, const float *bias, float *out,
+// First layer: Conv2d(1 -> 64, 3x3, pad 1) + folded BN + ReLU, fp32 input, NHWC output.  w9x64: [tap][cout].
+hipError_t launch_conv_first(const float *x, const float *w9x64, const float *bias, void *out, bool f16,
                              int N, int H, int W, hipStream_t st);
-// Last layer: Conv2d(64 -> 1, 1x1).
-hipError_t launch_conv_out(const float *in, const float *w64, float bias, float *out, long npix, hipStream_t st);
-// NHWC -> NCHW (parity-test export only).
-hipError_t launch_nhwc_to_nchw(const float *in, float *out, int N, int H, int W, int C, hipStream_t st);
+// Last layer: Conv2d(64 -> 1, 1x1), fp32 output.
+hipError_t launch_conv_out(const void *in, bool f16, const float *w64, float bias, float *out, long npix, hipStream_t st);
+// NHWC -> NCHW fp32 (parity-test export only).
+hipError_t launch_nhwc_to_nchw(const void *in, bool f16, float *out, int N, int H, int W, int C, hipStream_t st);
 
 hipError_t launch_stft_mag(const float *audio, int n_clips, long L, int n_fft, int hop, int center,
                            long n_frames, float *out, hipStream_t st);

@@ -4,19 +4,24 @@
 // (/root/reference/code/model.py:7-50): conv3x3+BatchNorm+ReLU, MaxPool2d(2), ConvTranspose2d(2,2),
 // F.pad + torch.cat, and the first (Cin=1) and last (1x1, Cout=1) convolutions (model.py:56,68).
 //
-// Layout: activations are NHWC fp32 inside the library (Cin = 1 at the entry and Cout = 1 at the exit make
-// NCHW == NHWC at the API boundary, so no transpose is ever materialised).
+// Layout: activations are NHWC inside the library (Cin = 1 at the entry and Cout = 1 at the exit make
+// NCHW == NHWC at the API boundary, so no transpose is ever materialised).  Every kernel is templated on the
+// storage type T: float (exact-fp32 path) or _Float16 (fp16 storage, fp16 MFMA with fp32 accumulation —
+// BASELINE configs[4]).
 //
-// conv_mfma_f32: implicit GEMM on the exact-fp32 matrix cores (v_mfma_f32_32x32x2_f32, 256 FLOP/clk/CU).
+// conv_mfma<T>: implicit GEMM on the matrix cores
+//     float     v_mfma_f32_32x32x2_f32   (256 FLOP/clk/CU, exact fp32)
+//     _Float16  v_mfma_f32_32x32x16_f16  (16x the fp32 rate, fp32 accumulate)
 //   GEMM rows    = pixels of a TH x 16 output tile (one 32-row MFMA block = 2 tile rows x 16 columns)
 //   GEMM columns = output channels (BN per workgroup)
 //   GEMM K       = taps x input channels, walked in chunks of KC channels: per chunk the input halo
 //                  ((TH+2) x 18 pixels x KC channels) and the 9 x KC x BN weight slab are staged in LDS once
 //                  and reused by all 9 taps — no im2col, each activation is fetched ~1.4x not 9x.
-//   K order inside an MFMA is free (A and B only have to agree), so each lane reads FOUR consecutive
-//   channels with one ds_read_b128 and feeds them to four MFMAs: lane (row r, half h) supplies channel
-//   c0 + 4h + kk at step kk.  Weights are pre-packed on the host in exactly the order the LDS image wants
-//   ([tap][kgroup][half][column][4]), so staging them is a linear copy and every B read is conflict-free.
+//   A "k-group" is 32 bytes of channels per pixel (8 floats / 16 halfs): lane (row r, half h) reads its 16-byte
+//   half with one ds_read_b128.  For fp32 the K order inside an MFMA is free (A and B only have to agree), so the
+//   four floats feed four 32x32x2 MFMAs (lane (r,h) supplies channel c0 + 4h + kk at step kk); for fp16 the eight
+//   halfs are exactly the A/B fragment of one 32x32x16 MFMA (k = 8h + j).  Byte geometry, LDS images and the
+//   host-side weight packing ([tap][kgroup][half][column][16 bytes]) are therefore identical for both types.
 //   Concat + pad of the up path is virtual: a chunk is fetched from the skip tensor or from the upsampled
 //   tensor (with its pad offset) — torch.cat / F.pad never touch memory.
 //   Epilogue: folded-BN bias + ReLU, NHWC store, and (down path) the 2x2 max-pool computed in-lane from
@@ -27,11 +32,17 @@ namespace adn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
 constexpr int TW = 16;       // tile width (pixels)
 constexpr int NTHREADS = 256;
+
+template <typename T> struct Elem;
+template <> struct Elem<float> { static constexpr int EPV = 4; };       // elements per 16-byte vector
+template <> struct Elem<_Float16> { static constexpr int EPV = 8; };
 
 // Bijective remap so that workgroups sharing an XCD (ids congruent mod 8, observed round-robin placement)
 // work on neighbouring tiles; affects speed only, never results.
@@ -42,19 +53,20 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg)
     return start + (b >> 3);
 }
 
-template <int TH, int BN, int WM, int WN, int TAPS, int KG, int EPI>
-__global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_f32(const ConvArgs p)
+template <typename T, int TH, int BN, int WM, int WN, int TAPS, int KG, int EPI>
+__global__ __launch_bounds__(NTHREADS, 2) void conv_mfma(const ConvArgs p)
 {
+    constexpr int EPV = Elem<T>::EPV;
     constexpr int HALO = (TAPS == 9) ? 1 : 0;
     constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
-    constexpr int KC = 8 * KG;
-    constexpr int KQ = KC / 4;                  // float4 per pixel per chunk
-    constexpr int ASTR = KC + 4;                // LDS floats per halo pixel (+4 pad: conflict-free b128 reads)
-    constexpr int A_FLOATS = PH * PW * ASTR;
-    constexpr int B_FLOATS = TAPS * KG * 2 * BN * 4;
+    constexpr int KC = 2 * EPV * KG;            // channels per chunk (8*KG floats or 16*KG halfs = 32*KG bytes)
+    constexpr int KQ = 2 * KG;                  // 16-byte vectors per pixel per chunk
+    constexpr int ASTR = 8 * KG + 4;            // LDS dwords per halo pixel (+16 B pad: conflict-free b128 reads)
+    constexpr int A_DW = PH * PW * ASTR;
+    constexpr int B_DW = TAPS * KG * 2 * BN * 4;
     constexpr int A_ITEMS = PH * PW * KQ;
     constexpr int A_ROUNDS = (A_ITEMS + NTHREADS - 1) / NTHREADS;
-    constexpr int B_ITEMS = B_FLOATS / 4;
+    constexpr int B_ITEMS = B_DW / 4;
     constexpr int B_ROUNDS = (B_ITEMS + NTHREADS - 1) / NTHREADS;
     constexpr int MB = TH * TW / 32 / WM;       // 32-row MFMA blocks per wave
     constexpr int NB = BN / 32 / WN;            // 32-column MFMA blocks per wave
@@ -63,7 +75,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_f32(const ConvArgs p)
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *sA = smem;
-    float *sB = smem + A_FLOATS;
+    float *sB = smem + A_DW;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -81,7 +93,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_f32(const ConvArgs p)
     const int gy0 = ty * TH - HALO, gx0 = tx * TW - HALO;
 
     // ---- per-thread staging plan for the halo (fixed over the chunk loop) ----
-    int aoff0[A_ROUNDS], aoff1[A_ROUNDS], alds[A_ROUNDS];
+    // hcur = element offsets into the source of the NEXT chunk to fetch, hsec = into the second source (virtual
+    // concat); two plain arrays switched once at chunk nchunk0 (a `first ? a[r] : b[r]` select makes hipcc build a
+    // runtime-indexed stack array, i.e. scratch traffic inside the loop).
+    int hcur[A_ROUNDS], hsec[A_ROUNDS], alds[A_ROUNDS];
 #pragma unroll
     for (int r = 0; r < A_ROUNDS; ++r) {
         const int item = tid + r * NTHREADS;
@@ -91,36 +106,38 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_f32(const ConvArgs p)
         const bool in_range = (A_ITEMS % NTHREADS == 0) || item < A_ITEMS;
         alds[r] = in_range ? pix * ASTR + q * 4 : -1;
         const int y0 = gy - p.s0.offY, x0 = gx - p.s0.offX;
-        aoff0[r] = (in_range && y0 >= 0 && y0 < p.s0.H && x0 >= 0 && x0 < p.s0.W)
-                       ? (y0 * p.s0.W + x0) * p.s0.C + q * 4 : -1;
+        hcur[r] = (in_range && y0 >= 0 && y0 < p.s0.H && x0 >= 0 && x0 < p.s0.W)
+                      ? (y0 * p.s0.W + x0) * p.s0.C + q * EPV : -1;
         const int y1 = gy - p.s1.offY, x1 = gx - p.s1.offX;
-        aoff1[r] = (in_range && y1 >= 0 && y1 < p.s1.H && x1 >= 0 && x1 < p.s1.W)
-                       ? (y1 * p.s1.W + x1) * p.s1.C + q * 4 : -1;
+        hsec[r] = (in_range && y1 >= 0 && y1 < p.s1.H && x1 >= 0 && x1 < p.s1.W)
+                      ? (y1 * p.s1.W + x1) * p.s1.C + q * EPV : -1;
     }
-    const float *base0 = p.s0.ptr + (size_t)n * p.s0.H * p.s0.W * p.s0.C;
-    const float *base1 = p.s1.ptr + (size_t)n * p.s1.H * p.s1.W * p.s1.C;
-    const float *wbase = p.wpk + (size_t)ct * p.nchunk * B_FLOATS;
+    const T *srcp = static_cast<const T *>(p.s0.ptr) + (size_t)n * p.s0.H * p.s0.W * p.s0.C;
+    const T *base1 = static_cast<const T *>(p.s1.ptr) + (size_t)n * p.s1.H * p.s1.W * p.s1.C;
+    const float *wp = static_cast<const float *>(p.wpk) + (size_t)ct * p.nchunk * B_DW;
 
     f32x4 ra[A_ROUNDS], rb[B_ROUNDS];
 
 #define ADN_PREFETCH(c)                                                                        \
     do {                                                                                       \
-        const bool first_ = (c) < p.nchunk0;                                                   \
-        const float *src_ = first_ ? base0 + (c) * KC : base1 + ((c) - p.nchunk0) * KC;        \
+        if ((c) == p.nchunk0) {                       /* wave-uniform: switch to the second source */ \
+            srcp = base1;                                                                      \
+            _Pragma("unroll") for (int r = 0; r < A_ROUNDS; ++r) hcur[r] = hsec[r];            \
+        }                                                                                      \
         _Pragma("unroll") for (int r = 0; r < A_ROUNDS; ++r) {                                 \
-            const int off_ = first_ ? aoff0[r] : aoff1[r];                                     \
-            /* unconditional load from a clamped (always valid) offset, then select: a load under   */ \
-            /* a branch makes hipcc wait vmcnt(0) after EACH one, serialising the prefetch          */ \
-            f32x4 v_ = *reinterpret_cast<const f32x4 *>(src_ + (off_ >= 0 ? off_ : 0));             \
-            if (off_ < 0) v_ = f32x4{0.f, 0.f, 0.f, 0.f};                                          \
+            /* unconditional load from a clamped (always valid) offset, then select: a load under a */ \
+            /* branch makes hipcc wait vmcnt(0) after EACH one, serialising the prefetch            */ \
+            f32x4 v_ = *reinterpret_cast<const f32x4 *>(srcp + (hcur[r] >= 0 ? hcur[r] : 0));  \
+            if (hcur[r] < 0) v_ = f32x4{0.f, 0.f, 0.f, 0.f};                                   \
             ra[r] = v_;                                                                        \
         }                                                                                      \
-        const float *w_ = wbase + (size_t)(c) * B_FLOATS;                                      \
         _Pragma("unroll") for (int r = 0; r < B_ROUNDS; ++r) {                                 \
             const int item_ = tid + r * NTHREADS;                                              \
             const int citem_ = (B_ITEMS % NTHREADS == 0 || item_ < B_ITEMS) ? item_ : 0;       \
-            rb[r] = *reinterpret_cast<const f32x4 *>(w_ + citem_ * 4);   /* no branch, see above */ \
+            rb[r] = *reinterpret_cast<const f32x4 *>(wp + citem_ * 4);                         \
         }                                                                                      \
+        srcp += KC;                                                                            \
+        wp += B_DW;                                                                            \
     } while (0)
 
     // bias is fetched BEFORE the main loop: a load still pending in the epilogue makes hipcc wait vmcnt(0) inside
@@ -137,7 +154,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_f32(const ConvArgs p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // LDS read bases (floats)
+    // LDS read bases (dwords)
     const int a_lane = ((wm * MB * 2 + ((lane >> 4) & 1)) * PW + (lane & 15)) * ASTR + hh * 4;
     const int b_lane = hh * BN * 4 + (wn * NB * 32 + l31) * 4;
 
@@ -168,13 +185,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_f32(const ConvArgs p)
 #pragma unroll
                 for (int j = 0; j < NB; ++j)
                     b[j] = *reinterpret_cast<const f32x4 *>(sB + b_lane + j * 128 + (tap * KG + s) * 2 * BN * 4);
+                if constexpr (sizeof(T) == 4) {
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
+                    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                        for (int i = 0; i < MB; ++i)
+#pragma unroll
+                            for (int j = 0; j < NB; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], b[j][kk], acc[i][j], 0, 0, 0);
+                } else {
 #pragma unroll
                     for (int i = 0; i < MB; ++i)
 #pragma unroll
                         for (int j = 0; j < NB; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], b[j][kk], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[i]),
+                                                                               __builtin_bit_cast(f16x8, b[j]), acc[i][j], 0, 0, 0);
+                }
             }
         }
     }
@@ -183,6 +209,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_f32(const ConvArgs p)
     // ---- epilogue ----
     // accumulator register r of lane (hh, l31): GEMM row m = (r&3) + 8*(r>>2) + 4*hh, column l31.
     // row m of m-block i -> tile pixel (trow, tcol) = ((wm*MB+i)*2 + (m>>4), m&15).
+    T *outp = static_cast<T *>(p.out);
+    T *poolp = static_cast<T *>(p.pool);
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         const int col = ct * BN + (wn * NB + j) * 32 + l31;     // GEMM column
@@ -194,30 +222,30 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_f32(const ConvArgs p)
                 // column = (di*2+dj)*Cout + co ; output pixel (2*gy+di, 2*gx+dj); bias only, no activation.
                 const int ij = col / p.Cout, co = col - ij * p.Cout;
                 const int Ho = 2 * p.H, Wo = 2 * p.W;
-                float *ob = p.out + (size_t)n * Ho * Wo * p.Cout + co;
+                T *ob = outp + (size_t)n * Ho * Wo * p.Cout + co;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = (r & 3) + 8 * (r >> 2) + 4 * hh;
                     const int gy = ty * TH + trow0 + (m >> 4), gx = tx * TW + (m & 15);
                     if (gy < p.H && gx < p.W)
-                        ob[((size_t)(2 * gy + (ij >> 1)) * Wo + (2 * gx + (ij & 1))) * p.Cout] = acc[i][j][r] + bv;
+                        ob[((size_t)(2 * gy + (ij >> 1)) * Wo + (2 * gx + (ij & 1))) * p.Cout] = (T)(acc[i][j][r] + bv);
                 }
             } else {
                 float v[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc[i][j][r] + bv, 0.f);
-                float *ob = p.out + (size_t)n * p.H * p.W * p.Cout + col;
+                T *ob = outp + (size_t)n * p.H * p.W * p.Cout + col;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = (r & 3) + 8 * (r >> 2) + 4 * hh;
                     const int gy = ty * TH + trow0 + (m >> 4), gx = tx * TW + (m & 15);
-                    if (gy < p.H && gx < p.W) ob[((size_t)gy * p.W + gx) * p.Cout] = v[r];
+                    if (gy < p.H && gx < p.W) ob[((size_t)gy * p.W + gx) * p.Cout] = (T)v[r];
                 }
                 if (EPI == CONV3X3_RELU_POOL) {
                     // 2x2 window (rows trow0, trow0+1; cols tcol, tcol+1 with tcol even) = registers
                     // (q,pp), (q,pp+1), (q+2,pp), (q+2,pp+1) with r = 4q+pp, q in {0,1}, pp in {0,2}.
                     const int Hp = p.H >> 1, Wp = p.W >> 1;
-                    float *pb = p.pool + (size_t)n * Hp * Wp * p.Cout + col;
+                    T *pb = poolp + (size_t)n * Hp * Wp * p.Cout + col;
                     const int py = (ty * TH + trow0) >> 1;
 #pragma unroll
                     for (int q = 0; q < 2; ++q)
@@ -226,7 +254,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_f32(const ConvArgs p)
                             const float m4 = fmaxf(fmaxf(v[4 * q + pp], v[4 * q + pp + 1]),
                                                    fmaxf(v[4 * (q + 2) + pp], v[4 * (q + 2) + pp + 1]));
                             const int px = ((tx * TW) >> 1) + (pp >> 1) + 2 * hh + 4 * q;
-                            if (py < Hp && px < Wp) pb[((size_t)py * Wp + px) * p.Cout] = m4;
+                            if (py < Hp && px < Wp) pb[((size_t)py * Wp + px) * p.Cout] = (T)m4;
                         }
                 }
             }
@@ -236,11 +264,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_f32(const ConvArgs p)
 
 // ------------------------------------------------------------------------------------------------
 // First layer: Conv2d(1 -> 64, 3x3, pad 1) + folded BN + ReLU (model.py:11-13 via :56).  HBM-bound
-// (4.4 FLOP/B): 16 lanes share a pixel, each lane owns 4 output channels (float4 store, 1 KiB per wave
-// store instruction, fully coalesced); weights live in registers.
+// (4.4 FLOP/B): 16 lanes share a pixel, each lane owns 4 output channels (16-byte store for fp32, 8-byte for
+// fp16; a wave store instruction covers 4 pixels contiguously); weights live in registers.  Input is always fp32.
 // ------------------------------------------------------------------------------------------------
+template <typename T>
 __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict__ x, const float *__restrict__ w9x64,
-                                                         const float *__restrict__ bias, float *__restrict__ out,
+                                                         const float *__restrict__ bias, T *__restrict__ out,
                                                          int N, int H, int W, long npix)
 {
     const int q = threadIdx.x & 15;       // channel group: couts 4q .. 4q+3
@@ -265,13 +294,18 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict
                 a += wv[dy * 3 + dx] * v;
             }
         a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
-        *reinterpret_cast<f32x4 *>(out + pix * 64 + q * 4) = a;
+        if constexpr (sizeof(T) == 4) {
+            *reinterpret_cast<f32x4 *>(out + pix * 64 + q * 4) = a;
+        } else {
+            *reinterpret_cast<f16x4 *>(out + pix * 64 + q * 4) = f16x4{(_Float16)a.x, (_Float16)a.y, (_Float16)a.z, (_Float16)a.w};
+        }
     }
 }
 
-// Last layer: Conv2d(64 -> 1, 1x1) (model.py:68,93).  HBM-bound: 16 lanes per pixel read one float4 each
-// (1 KiB per wave load instruction), 4-step xor-shuffle reduction inside the 16-lane group.
-__global__ __launch_bounds__(256) void conv_out_kernel(const float *__restrict__ in, const float *__restrict__ w64,
+// Last layer: Conv2d(64 -> 1, 1x1) (model.py:68,93).  HBM-bound: 16 lanes per pixel read 4 channels each,
+// 4-step xor-shuffle reduction inside the 16-lane group.  Output is always fp32.
+template <typename T>
+__global__ __launch_bounds__(256) void conv_out_kernel(const T *__restrict__ in, const float *__restrict__ w64,
                                                        float bias, float *__restrict__ out, long npix)
 {
     const int q = threadIdx.x & 15;
@@ -282,7 +316,14 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const float *__restrict__
     for (long base = (long)blockIdx.x * 16; base < npix; base += step) {
         const long pix = base + slot;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (pix < npix) v = *reinterpret_cast<const f32x4 *>(in + pix * 64 + q * 4);
+        if (pix < npix) {
+            if constexpr (sizeof(T) == 4) {
+                v = *reinterpret_cast<const f32x4 *>(in + pix * 64 + q * 4);
+            } else {
+                const f16x4 hv = *reinterpret_cast<const f16x4 *>(in + pix * 64 + q * 4);
+                v = f32x4{(float)hv.x, (float)hv.y, (float)hv.z, (float)hv.w};
+            }
+        }
         float s = v.x * wv.x + v.y * wv.y + v.z * wv.z + v.w * wv.w;
         s += __shfl_xor(s, 8, 64);
         s += __shfl_xor(s, 4, 64);
@@ -292,8 +333,9 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const float *__restrict__
     }
 }
 
-// NHWC -> NCHW through a 32x33 LDS tile (parity-test export only).
-__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float *__restrict__ in, float *__restrict__ out,
+// NHWC (T) -> NCHW (fp32) through a 32x33 LDS tile (parity-test export only).
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T *__restrict__ in, float *__restrict__ out,
                                                            long HW, int C)
 {
     __shared__ float tile[32][33];
@@ -304,7 +346,7 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float *__restri
     for (int k = ty; k < 32; k += 8) {
         const long pp = p0 + k;
         const int c = c0 + tx;
-        tile[k][tx] = (pp < HW && c < C) ? in[(n * HW + pp) * C + c] : 0.f;
+        tile[k][tx] = (pp < HW && c < C) ? (float)in[(n * HW + pp) * C + c] : 0.f;
     }
     __syncthreads();
     for (int k = ty; k < 32; k += 8) {
@@ -314,69 +356,82 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float *__restri
     }
 }
 
-template <int TH, int BN, int WM, int WN, int TAPS, int KG, int EPI>
+template <typename T, int TH, int BN, int WM, int WN, int TAPS, int KG, int EPI>
 hipError_t launch_cfg(const ConvArgs &a, hipStream_t st)
 {
     constexpr int HALO = (TAPS == 9) ? 1 : 0;
     constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
-    constexpr int KC = 8 * KG;
-    constexpr size_t lds = (size_t)(PH * PW * (KC + 4) + TAPS * KG * 2 * BN * 4) * sizeof(float);
+    constexpr size_t lds = (size_t)(PH * PW * (8 * KG + 4) + TAPS * KG * 2 * BN * 4) * sizeof(float);
     const long nwg = (long)a.N * a.tilesY * a.tilesX * a.nct;
     if (nwg <= 0 || nwg > 0x7fffffffL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((conv_mfma_f32<TH, BN, WM, WN, TAPS, KG, EPI>), dim3((unsigned)nwg), dim3(NTHREADS), lds, st, a);
+    hipLaunchKernelGGL((conv_mfma<T, TH, BN, WM, WN, TAPS, KG, EPI>), dim3((unsigned)nwg), dim3(NTHREADS), lds, st, a);
     return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_conv_mfma_t(ConvKind kind, const ConvArgs &a, hipStream_t st)
+{
+    if (kind == CONVT2X2) return launch_cfg<T, 8, 128, 2, 2, 1, 4, CONVT2X2>(a, st);
+    if (a.Cout == 64) {
+        if (kind == CONV3X3_RELU_POOL) return launch_cfg<T, 16, 64, 4, 1, 9, 1, CONV3X3_RELU_POOL>(a, st);
+        return launch_cfg<T, 16, 64, 4, 1, 9, 1, CONV3X3_RELU>(a, st);
+    }
+    if (kind == CONV3X3_RELU_POOL) return launch_cfg<T, 8, 128, 2, 2, 9, 1, CONV3X3_RELU_POOL>(a, st);
+    return launch_cfg<T, 8, 128, 2, 2, 9, 1, CONV3X3_RELU>(a, st);
 }
 
 }  // namespace
 
-ConvGeom conv_geom(ConvKind kind, int Cout)
+// Tile geometry; KC is in CHANNELS and therefore depends on the storage type (one k-group = 32 bytes per pixel).
+ConvGeom conv_geom(ConvKind kind, int Cout, bool f16)
 {
-    if (kind == CONVT2X2) return ConvGeom{8, 128, 32};
-    if (Cout == 64) return ConvGeom{16, 64, 8};
-    return ConvGeom{8, 128, 8};
+    const int cpg = f16 ? 16 : 8;                // channels per k-group
+    if (kind == CONVT2X2) return ConvGeom{8, 128, 4 * cpg};
+    if (Cout == 64) return ConvGeom{16, 64, cpg};
+    return ConvGeom{8, 128, cpg};
 }
 
-size_t conv_packed_floats_per_chunk(ConvKind kind, int Cout)
+hipError_t launch_conv_mfma(ConvKind kind, const ConvArgs &a, bool f16, hipStream_t st)
 {
-    const ConvGeom g = conv_geom(kind, Cout);
-    const int taps = kind == CONVT2X2 ? 1 : 9;
-    return (size_t)taps * (g.KC / 8) * 2 * g.BN * 4;
+    return f16 ? launch_conv_mfma_t<_Float16>(kind, a, st) : launch_conv_mfma_t<float>(kind, a, st);
 }
 
-hipError_t launch_conv_mfma(ConvKind kind, const ConvArgs &a, hipStream_t st)
-{
-    if (kind == CONVT2X2) return launch_cfg<8, 128, 2, 2, 1, 4, CONVT2X2>(a, st);
-    if (a.Cout == 64) {
-        if (kind == CONV3X3_RELU_POOL) return launch_cfg<16, 64, 4, 1, 9, 1, CONV3X3_RELU_POOL>(a, st);
-        return launch_cfg<16, 64, 4, 1, 9, 1, CONV3X3_RELU>(a, st);
-    }
-    if (kind == CONV3X3_RELU_POOL) return launch_cfg<8, 128, 2, 2, 9, 1, CONV3X3_RELU_POOL>(a, st);
-    return launch_cfg<8, 128, 2, 2, 9, 1, CONV3X3_RELU>(a, st);
-}
-
-hipError_t launch_conv_first(const float *x, const float *w9x64, const float *bias, float *out,
+hipError_t launch_conv_first(const float *x, const float *w9x64, const float *bias, void *out, bool f16,
                              int N, int H, int W, hipStream_t st)
 {
     const long npix = (long)N * H * W;
     long blocks = (npix + 15) / 16;
     if (blocks > 256L * 32) blocks = 256L * 32;
-    hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, w9x64, bias, out, N, H, W, npix);
+    if (f16)
+        hipLaunchKernelGGL(conv_first_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), 0, st, x, w9x64, bias,
+                           static_cast<_Float16 *>(out), N, H, W, npix);
+    else
+        hipLaunchKernelGGL(conv_first_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, x, w9x64, bias,
+                           static_cast<float *>(out), N, H, W, npix);
     return hipGetLastError();
 }
 
-hipError_t launch_conv_out(const float *in, const float *w64, float bias, float *out, long npix, hipStream_t st)
+hipError_t launch_conv_out(const void *in, bool f16, const float *w64, float bias, float *out, long npix, hipStream_t st)
 {
     long blocks = (npix + 15) / 16;
     if (blocks > 256L * 32) blocks = 256L * 32;
-    hipLaunchKernelGGL(conv_out_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, w64, bias, out, npix);
+    if (f16)
+        hipLaunchKernelGGL(conv_out_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), 0, st,
+                           static_cast<const _Float16 *>(in), w64, bias, out, npix);
+    else
+        hipLaunchKernelGGL(conv_out_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st,
+                           static_cast<const float *>(in), w64, bias, out, npix);
     return hipGetLastError();
 }
 
-hipError_t launch_nhwc_to_nchw(const float *in, float *out, int N, int H, int W, int C, hipStream_t st)
+hipError_t launch_nhwc_to_nchw(const void *in, bool f16, float *out, int N, int H, int W, int C, hipStream_t st)
 {
     const long HW = (long)H * W;
     dim3 grid((unsigned)((HW + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)N);
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, st, in, out, HW, C);
+    if (f16)
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<_Float16>, grid, dim3(256), 0, st, static_cast<const _Float16 *>(in), out, HW, C);
+    else
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, dim3(256), 0, st, static_cast<const float *>(in), out, HW, C);
     return hipGetLastError();
 }
 

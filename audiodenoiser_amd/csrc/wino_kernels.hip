@@ -128,9 +128,9 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
         const int y1 = gy - p.s1.offY, x1 = gx - p.s1.offX;
         hsec[r] = (data && y1 >= 0 && y1 < p.s1.H && x1 >= 0 && x1 < p.s1.W) ? (y1 * p.s1.W + x1) * p.s1.C + part * 4 : -1;
     }
-    const float *srcp = p.s0.ptr + (size_t)n * p.s0.H * p.s0.W * p.s0.C;    // channel window of the next chunk
-    const float *base1 = p.s1.ptr + (size_t)n * p.s1.H * p.s1.W * p.s1.C;
-    const float *wp = p.wpk + (size_t)ct * p.nchunk * 4096 + tid * 4;
+    const float *srcp = static_cast<const float *>(p.s0.ptr) + (size_t)n * p.s0.H * p.s0.W * p.s0.C;   // next chunk's channels
+    const float *base1 = static_cast<const float *>(p.s1.ptr) + (size_t)n * p.s1.H * p.s1.W * p.s1.C;
+    const float *wp = static_cast<const float *>(p.wpk) + (size_t)ct * p.nchunk * 4096 + tid * 4;
     const float *zsrc = p.zeros;
 
 #define ADN_DMA_BEGIN(c)                                                                       \
@@ -310,8 +310,8 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
     for (int j = 0; j < 2; ++j) {
         const int col = ct * WBN + 16 * j + ti;
         const float bv = bias_r[j];
-        float *ob = p.out + (size_t)n * p.H * p.W * p.Cout + col;
-        float *pb = (EPI == CONV3X3_RELU_POOL) ? p.pool + (size_t)n * Hp * Wp * p.Cout + col : nullptr;
+        float *ob = static_cast<float *>(p.out) + (size_t)n * p.H * p.W * p.Cout + col;
+        float *pb = (EPI == CONV3X3_RELU_POOL) ? static_cast<float *>(p.pool) + (size_t)n * Hp * Wp * p.Cout + col : nullptr;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int tile = 4 * q + r;

@@ -102,6 +102,8 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch-per-gpu", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", choices=("f32", "f16"), default="f32",
+                    help="f32 = headline metric (default); f16 = BASELINE configs[4] (fp16 storage + fp16 MFMA)")
     args = ap.parse_args()
 
     from audiodenoiser_amd import _lib
@@ -122,7 +124,8 @@ def main() -> None:
     sd_np = make_state_dict(1234)                                     # replicated weights, regenerated per rank
     net = UNet(1, 1)
     net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd_np.items()}, strict=True)
-    net = net.to(dev).eval()
+    net = net.to(dev).eval().set_compute_dtype(args.dtype)
+    f16 = args.dtype == "f16"
 
     b = args.batch_per_gpu
     g = torch.Generator(device=dev).manual_seed(rank)                 # per-rank shard of the global batch
@@ -159,12 +162,14 @@ def main() -> None:
 
     if rank == 0:
         launches = unet_launches(F_BINS, T_FRAMES)
+        peak = 2516.6 if f16 else PEAK_MFMA_F32_TFLOPS      # dense MFMA peak of the arithmetic type (MI355X_MICROARCH.md)
+        direct = f16 or os.environ.get("ADN_CONV_ALGO") == "direct"
         dom = [i for i, l in enumerate(launches) if l["kind"] == "conv3x3"]
         dom_flops = sum(launches[i]["flops"] for i in dom) * b          # per forward of this rank
         dom_ms = float(ms_mean[dom].sum())
         achieved = dom_flops / (dom_ms * 1e-3) / 1e12
         tot_flops = sum(l["flops"] for l in launches) * b
-        tot_bytes = sum(l["act_bytes"] for l in launches) * b + sum(l["weight_bytes"] for l in launches)
+        tot_bytes = (sum(l["act_bytes"] for l in launches) * b + sum(l["weight_bytes"] for l in launches)) * (0.5 if f16 else 1.0)
         fwd_ms = float(ms_mean.sum())
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -186,23 +191,25 @@ def main() -> None:
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": f"batch={b} per GPU synthetic 513x256 fp32 spectrograms, full U-Net forward "
+                                   + ("[fp16 storage + fp16 MFMA inside, BASELINE configs[4]] " if f16 else "")
+                                   +
                                    "(BASELINE configs[1]) + per-clip perceptual loss" + (" + all-gather" if world > 1 else ""),
                        "batch_per_gpu": b, "global_batch": b * world, "freq_bins": F_BINS, "frames": T_FRAMES,
                        "parallelism": f"clips sharded over {world} rank(s), weights replicated"},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_MFMA_F32_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_F32_TFLOPS, 4), "traffic": traffic,
-                         "kernel": ("conv_mfma_f32 (direct implicit GEMM)" if os.environ.get("ADN_CONV_ALGO") == "direct"
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
+                         "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None if direct else traffic,
+                         "kernel": (("conv_mfma<f16> (direct implicit GEMM, fp16 MFMA)" if f16 else
+                                     "conv_mfma<f32> (direct implicit GEMM)") if direct
                                     else "wino_conv_dma_f32 (Winograd F(2x2,3x3), fp32 MFMA)") + ", 17 launches per forward",
-                         "mfma_util": round(achieved / PEAK_MFMA_F32_TFLOPS /
-                                            (1.0 if os.environ.get("ADN_CONV_ALGO") == "direct" else 2.25), 4),
+                         "mfma_util": round(achieved / peak / (1.0 if direct else 2.25), 4),
                          "flops_per_launch": round(dom_flops / len(dom), 1),
                          "avg_launch_ms": round(dom_ms / len(dom), 4)},
             "forward": {"kernel_ms": round(fwd_ms, 3),
                         "tflops": round(tot_flops / (fwd_ms * 1e-3) / 1e12, 2),
-                        "frac_mfma_peak": round(tot_flops / (fwd_ms * 1e-3) / 1e12 / PEAK_MFMA_F32_TFLOPS, 4),
+                        "frac_mfma_peak": round(tot_flops / (fwd_ms * 1e-3) / 1e12 / peak, 4),
                         "algorithmic_GBps": round(tot_bytes / (fwd_ms * 1e-3) / 1e9, 1),
                         "frac_hbm_peak": round(tot_bytes / (fwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                         "per_launch_ms": {l["name"]: round(float(m), 4) for l, m in zip(launches, ms_mean)}},

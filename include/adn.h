@@ -54,9 +54,16 @@ int adn_device_count(int *count);
  * This is the weight format of the reference checkpoint (train.py:142, test.py:65).  BatchNorm (eval mode,
  * eps 1e-5) is folded into the preceding convolution here.  Synchronous. */
 int adn_unet_create(adn_unet **handle, int device, const float *const *host_tensors, int n_tensors);
+/* Same with an explicit arithmetic type.  ADN_DTYPE_F32 (= adn_unet_create): exact-fp32 matrix cores.
+ * ADN_DTYPE_F16 (BASELINE configs[4]): activations and weights stored in fp16 inside the library, fp16 MFMA
+ * with fp32 accumulation; x and y stay fp32 at the boundary; outputs within 1e-2 of the fp32 path. */
+#define ADN_DTYPE_F32 0
+#define ADN_DTYPE_F16 1
+int adn_unet_create_ex(adn_unet **handle, int device, const float *const *host_tensors, int n_tensors, int dtype);
 int adn_unet_destroy(adn_unet *handle);
 
-/* Bytes of device scratch adn_unet_forward needs for an (N,1,F,T) batch. */
+/* Bytes of device scratch adn_unet_forward needs for an (N,1,F,T) batch (half as much for an fp16 handle;
+ * handle may be NULL = fp32). */
 int adn_unet_workspace_bytes(const adn_unet *handle, int N, int F, int T, size_t *bytes);
 
 /* y(N,1,F,T) = UNet(x(N,1,F,T)), eval-mode semantics (BatchNorm uses running statistics), fp32.

@@ -322,3 +322,45 @@ def test_perceptual_loss_zero_and_errors(dev):
     from audiodenoiser_amd._lib import AdnError
     with pytest.raises(AdnError):
         perceptual_loss_per_clip(x[..., :32].contiguous(), x[..., :32].contiguous())     # T < 64
+
+
+# ---------------------------------------------------------------------------------------------- fp16 path
+def test_fp16_path_within_1e2_of_fp32_reference(dev, weights_np, golden_dir):
+    """BASELINE configs[4]: fp16 storage + fp16 MFMA (fp32 accumulate); outputs within 1e-2 (relative to max|ref|)
+    of the fp32 reference goldens, on every golden shape, and block outputs within 1e-2 of their rms."""
+    from audiodenoiser_amd.model import UNet
+    from audiodenoiser_amd.weights import make_input
+    m = UNet(1, 1)
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in weights_np.items()}, strict=True)
+    m = m.to(dev).eval().set_compute_dtype("f16")
+    for (n, f, t) in GOLDEN_SHAPES:
+        g = np.load(os.path.join(golden_dir, f"unet_{f}x{t}.npz"))
+        with torch.no_grad():
+            y, taps = m(torch.from_numpy(make_input(7, n, f, t)).to(dev), return_taps=True)
+        assert y.dtype == torch.float32
+        assert _rel(y.cpu().numpy(), g["y"]) <= 1e-2, (f, t)
+        for name, tp in taps.items():
+            a = tp.cpu().numpy().astype(np.float64).ravel()
+            s_, sa, sq, cnt = g[f"{name}_stats"]
+            rms = np.sqrt(sq / cnt)
+            assert np.abs(a[g[f"{name}_idx"]] - g[f"{name}_val"]).max() <= 5e-2 * rms, name
+            assert abs(np.abs(a).sum() - sa) <= 1e-2 * sa, name
+
+
+def test_fp16_path_batch256(dev, weights_np):
+    """configs[4] at its stated size, batch 256 x 513x256: finite, clip independent, and two clips within 1e-2 of
+    the fp32 HIP path (itself within 1e-4 of the reference)."""
+    from audiodenoiser_amd.model import UNet
+    m = UNet(1, 1)
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in weights_np.items()}, strict=True)
+    m = m.to(dev).eval().set_compute_dtype("f16")
+    g = torch.Generator(device=dev).manual_seed(3)
+    x = torch.rand((256, 1, 513, 256), generator=g, device=dev) * 4.0
+    with torch.no_grad():
+        y = m(x)
+        assert torch.isfinite(y).all()
+        assert torch.equal(m(x[100:101].clone())[0], y[100])
+        m.set_compute_dtype("f32")
+        for i in (0, 255):
+            ref = m(x[i:i + 1].clone())
+            assert float((y[i:i + 1] - ref).abs().max() / ref.abs().max()) <= 1e-2
