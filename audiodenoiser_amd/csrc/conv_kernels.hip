@@ -264,40 +264,63 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma(const ConvArgs p)
 
 // ------------------------------------------------------------------------------------------------
 // First layer: Conv2d(1 -> 64, 3x3, pad 1) + folded BN + ReLU (model.py:11-13 via :56).  HBM-bound
-// (4.4 FLOP/B): 16 lanes share a pixel, each lane owns 4 output channels (16-byte store for fp32, 8-byte for
-// fp16; a wave store instruction covers 4 pixels contiguously); weights live in registers.  Input is always fp32.
+// (4.4 FLOP/B, write-dominated: 64 output floats per input float).  Vector loads queue behind the same CU's
+// outstanding stores (measured with tools/ubench/first_layer.hip: the per-strip global-load form ran at 2.9 TB/s,
+// the same kernel without loads at 5.6), so a workgroup fetches the (FIRST_ROWS+2) x (W+2) input window of its
+// FIRST_ROWS image rows ONCE into LDS and then only stores: 16 lanes share a strip of FIRST_PX pixels, each lane
+// owns 4 output channels (16-byte store for fp32, 8-byte for fp16), reads its 3 x (FIRST_PX+2) window from LDS
+// (a path of its own) and keeps the weights in registers.  Input is always fp32.
 // ------------------------------------------------------------------------------------------------
+constexpr int FIRST_PX = 8, FIRST_ROWS = 8;
+
 template <typename T>
 __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict__ x, const float *__restrict__ w9x64,
                                                          const float *__restrict__ bias, T *__restrict__ out,
-                                                         int N, int H, int W, long npix)
+                                                         int H, int W, int tiles_per_img)
 {
-    const int q = threadIdx.x & 15;       // channel group: couts 4q .. 4q+3
-    const int slot = threadIdx.x >> 4;    // 16 pixels per pass
+    extern __shared__ float s_win[];               // (FIRST_ROWS+2) rows x (W+2), zero halo
+    const int q = threadIdx.x & 15;               // channel group: couts 4q .. 4q+3
+    const int slot = threadIdx.x >> 4;            // 16 strips per pass
+    const int n = blockIdx.x / tiles_per_img;
+    const int y0 = (blockIdx.x - n * tiles_per_img) * FIRST_ROWS;
+    const int WP = W + 2;
+    const float *xp = x + (long)n * H * W;
+    for (int i = threadIdx.x; i < (FIRST_ROWS + 2) * WP; i += 256) {
+        const int r = i / WP, c = i - r * WP;
+        const int yy = y0 + r - 1, xx = c - 1;
+        s_win[i] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? xp[(long)yy * W + xx] : 0.f;
+    }
     f32x4 wv[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const f32x4 *>(w9x64 + t * 64 + q * 4);
     const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + q * 4);
-    const long HW = (long)H * W;
-    for (long pix = (long)blockIdx.x * 16 + slot; pix < npix; pix += (long)gridDim.x * 16) {
-        const long n = pix / HW;
-        const int rem = (int)(pix - n * HW);
-        const int gy = rem / W, gx = rem - gy * W;
-        const float *xp = x + n * HW;
-        f32x4 a = bv;
+    __syncthreads();
+    const int spr = (W + FIRST_PX - 1) / FIRST_PX;              // strips per row
+    const int rows = min(FIRST_ROWS, H - y0);
+    for (int s = slot; s < rows * spr; s += 16) {
+        const int r = s / spr, x0 = (s - r * spr) * FIRST_PX;
+        float v[3][FIRST_PX + 2];
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const int yy = gy + dy - 1, xx = gx + dx - 1;
-                const float v = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? xp[(long)yy * W + xx] : 0.f;
-                a += wv[dy * 3 + dx] * v;
+            for (int j = 0; j < FIRST_PX + 2; ++j) v[dy][j] = s_win[(r + dy) * WP + min(x0 + j, WP - 1)];
+        T *op = out + (((long)n * H + y0 + r) * W + x0) * 64 + q * 4;
+#pragma unroll
+        for (int px = 0; px < FIRST_PX; ++px) {
+            f32x4 a = bv;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) a += wv[dy * 3 + dx] * v[dy][px + dx];
+            a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
+            if (x0 + px < W) {
+                if constexpr (sizeof(T) == 4) {
+                    *reinterpret_cast<f32x4 *>(op + px * 64) = a;
+                } else {
+                    *reinterpret_cast<f16x4 *>(op + px * 64) =
+                        f16x4{(_Float16)a.x, (_Float16)a.y, (_Float16)a.z, (_Float16)a.w};
+                }
             }
-        a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
-        if constexpr (sizeof(T) == 4) {
-            *reinterpret_cast<f32x4 *>(out + pix * 64 + q * 4) = a;
-        } else {
-            *reinterpret_cast<f16x4 *>(out + pix * 64 + q * 4) = f16x4{(_Float16)a.x, (_Float16)a.y, (_Float16)a.z, (_Float16)a.w};
         }
     }
 }
@@ -399,15 +422,22 @@ hipError_t launch_conv_mfma(ConvKind kind, const ConvArgs &a, bool f16, hipStrea
 hipError_t launch_conv_first(const float *x, const float *w9x64, const float *bias, void *out, bool f16,
                              int N, int H, int W, hipStream_t st)
 {
-    const long npix = (long)N * H * W;
-    long blocks = (npix + 15) / 16;
-    if (blocks > 256L * 32) blocks = 256L * 32;
+    const int tpi = (H + FIRST_ROWS - 1) / FIRST_ROWS;
+    const long blocks = (long)N * tpi;
+    const size_t lds = (size_t)(FIRST_ROWS + 2) * (W + 2) * sizeof(float);
+    if (blocks <= 0 || blocks > 0x7fffffffL || lds > 160 * 1024) return hipErrorInvalidValue;   // W <= 4094
+    if (lds > 64 * 1024) {
+        const void *fn = f16 ? reinterpret_cast<const void *>(conv_first_kernel<_Float16>)
+                             : reinterpret_cast<const void *>(conv_first_kernel<float>);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
     if (f16)
-        hipLaunchKernelGGL(conv_first_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), 0, st, x, w9x64, bias,
-                           static_cast<_Float16 *>(out), N, H, W, npix);
+        hipLaunchKernelGGL(conv_first_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), lds, st, x, w9x64, bias,
+                           static_cast<_Float16 *>(out), H, W, tpi);
     else
-        hipLaunchKernelGGL(conv_first_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, x, w9x64, bias,
-                           static_cast<float *>(out), N, H, W, npix);
+        hipLaunchKernelGGL(conv_first_kernel<float>, dim3((unsigned)blocks), dim3(256), lds, st, x, w9x64, bias,
+                           static_cast<float *>(out), H, W, tpi);
     return hipGetLastError();
 }
 
