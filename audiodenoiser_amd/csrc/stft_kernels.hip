@@ -240,6 +240,12 @@ __global__ __launch_bounds__(STFT_THREADS) void stft_mag_kernel(const float *__r
 // ------------------------------------------------------------------------------------------------
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
+// volatile LDS views: keep every exchange access a single ds_read_b64 / ds_write_b64 -- the merged two-address
+// forms (ds_read2_b64, ds_read2st64_b64) are served 16 lanes at a time over 32 banks at half the rate and would
+// break the bank analysis of xidx()
+typedef volatile v2f __attribute__((address_space(3))) lds_v_v2f;
+__device__ __forceinline__ v2f ADN_XRD(const v2f *p) { return *(const lds_v_v2f *)p; }
+__device__ __forceinline__ void ADN_XWR(v2f *p, v2f val) { *(lds_v_v2f *)p = val; }
 
 __device__ __forceinline__ v2f vmul(v2f a, v2f b)   // complex multiply, packed-math friendly
 {
@@ -284,7 +290,28 @@ __device__ __forceinline__ void vdft<8>(v2f *v)
     }
 }
 
-__device__ __forceinline__ int phys(int j) { return j + (j >> 3); }   // exchange image: 1 pad element per 8
+// Exchange-image layouts.  X = 1: written by pass 1, read by pass 2; X = 2: pass 2 -> pass 3; X = 3: last pass ->
+// real-FFT post-processing.  A ds_read_b64 is served in two groups of 32 lanes over 64 dword banks, a ds_write_b64 in
+// four groups of 16 lanes over 32 banks (MI355X_MICROARCH.md, LDS).  Every read here is "32 lanes, 32 consecutive
+// elements", so ANY permutation inside aligned 32-element blocks keeps the reads conflict-free, and the permutation
+// is chosen per exchange so that the 16 lanes of a write group hit 16 distinct element residues mod 16:
+//   M = 512 (BASELINE's n_fft 1024; one frame per wave):
+//     X = 1: writes 8t+q          -> e'[1:0] = e[4:3], e'[3:2] = e[1:0] ^ e[6:5], e'[4] = e[2]
+//     X = 2: writes 64(t>>3)+(t&7)+8q -> e' = e ^ (e[6] << 3)
+//     X = 3: writes t+64q, reads k and M-k -> identity
+//   other sizes: one pad element per 8 (reads of the later passes are then 2-way conflicted; not the headline size).
+template <int M, int X>
+__device__ __forceinline__ int xidx(int e)
+{
+    if constexpr (M == 512) {
+        if constexpr (X == 1) return (e & ~31) | ((e & 4) << 2) | ((((e & 3) ^ ((e >> 5) & 3))) << 2) | ((e >> 3) & 3);
+        else if constexpr (X == 2) return e ^ ((e >> 3) & 8);
+        else return e;
+    } else {
+        return e + (e >> 3);
+    }
+}
+template <int M> constexpr int exch_size() { return M == 512 ? M : M + M / 8; }
 
 __device__ __forceinline__ void wave_lds_fence()
 {
@@ -295,14 +322,14 @@ __device__ __forceinline__ void wave_lds_fence()
 
 // One Stockham pass (radix R, P = product of earlier radices) with the twiddles in registers `tw`
 // ((R-1) per butterfly, butterfly-major).
-template <int M, int R, int P>
+template <int M, int R, int P, int XIN, int XOUT>
 __device__ __forceinline__ void wave_pass(v2f *sc, const v2f *tw, int t, v2f *v)
 {
     constexpr int TPF = M / 8, NBF = 8 / R, T = M / R;
 #pragma unroll
     for (int b = 0; b < NBF; ++b)
 #pragma unroll
-        for (int u = 0; u < R; ++u) v[b * R + u] = sc[phys(t + b * TPF + u * T)];
+        for (int u = 0; u < R; ++u) v[b * R + u] = ADN_XRD(sc + xidx<M, XIN>(t + b * TPF + u * T));
     wave_lds_fence();
 #pragma unroll
     for (int b = 0; b < NBF; ++b) {
@@ -313,7 +340,7 @@ __device__ __forceinline__ void wave_pass(v2f *sc, const v2f *tw, int t, v2f *v)
         vdft<R>(v + b * R);
         const int j = (i - k) * R + k;
 #pragma unroll
-        for (int q = 0; q < R; ++q) sc[phys(j + q * P)] = v[b * R + q];
+        for (int q = 0; q < R; ++q) ADN_XWR(sc + xidx<M, XOUT>(j + q * P), v[b * R + q]);
     }
     wave_lds_fence();
 }
@@ -349,8 +376,9 @@ __device__ __forceinline__ int stft_xcd_remap(int b, int nwg)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
 }
 
-template <int M, int NW, int FPB>
-__global__ __launch_bounds__(NW * 64) void stft_wave_kernel(const float *__restrict__ audio, long L, int hop, int pad,
+// at least 3 waves per SIMD: the register allocation granule is 8, so 169 VGPRs would already drop to 2
+template <int M, int NW, int FPB, int WPE>
+__global__ __launch_bounds__(NW * 64, WPE) void stft_wave_kernel(const float *__restrict__ audio, long L, int hop, int pad,
                                                              long n_frames, int groups_per_clip, int gpb,
                                                              int blocks_per_clip, const float *__restrict__ tables,
                                                              float *__restrict__ out, int ablate)
@@ -358,7 +386,7 @@ __global__ __launch_bounds__(NW * 64) void stft_wave_kernel(const float *__restr
     constexpr int N = 2 * M, TPF = M / 8, NT = NW * 64;
     constexpr int SLOTS = NT / TPF, FPS = FPB / SLOTS;      // frames per slot and group, processed in sequence
     constexpr int MAGSTR = FPB + 1;
-    constexpr int SCSZ = M + M / 8;                          // padded exchange image (v2f elements)
+    constexpr int SCSZ = exch_size<M>();                     // exchange image (v2f elements), see xidx
     constexpr int R2 = WavePlan<M>::R2, R3 = WavePlan<M>::R3;
     static_assert(TPF <= 64 && FPB % SLOTS == 0 && FPS >= 1 && NT % FPB == 0, "bad STFT tiling");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -366,7 +394,10 @@ __global__ __launch_bounds__(NW * 64) void stft_wave_kernel(const float *__restr
     v2f *s_sc = reinterpret_cast<v2f *>(smem + (((M + 1) * MAGSTR + 1) & ~1));
 
     const int tid = threadIdx.x;
-    const int slot = tid / TPF, t = tid - slot * TPF;
+    // a frame per wave (TPF == 64): the slot is wave-uniform -> frame indices, bounds tests and the prefetch
+    // branches run on the scalar unit
+    const int slot = (TPF == 64) ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid / TPF;
+    const int t = tid - slot * TPF;
     const int lid = stft_xcd_remap(blockIdx.x, gridDim.x);
     const int clip = lid / blocks_per_clip;
     const int g_first = (lid - clip * blocks_per_clip) * gpb;
@@ -391,7 +422,7 @@ __global__ __launch_bounds__(NW * 64) void stft_wave_kernel(const float *__restr
     }
     v2f win[8], tw2[(R2 - 1) * (8 / R2)], tw3[R3 > 1 ? (R3 - 1) * (8 / R3) : 1], twp[4];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) win[u] = *reinterpret_cast<const v2f *>(s_mag + 2 * (t + u * TPF));
+    for (int u = 0; u < 8; ++u) win[u] = 0.5f * *reinterpret_cast<const v2f *>(s_mag + 2 * (t + u * TPF));   // Z/2, exact
     load_pass_twiddles<M, R2, 8>(s_mag, t, tw2);
     if constexpr (R3 > 1) load_pass_twiddles<M, R3, 8 * R2>(s_mag, t, tw3);
     {
@@ -458,46 +489,73 @@ __global__ __launch_bounds__(NW * 64) void stft_wave_kernel(const float *__restr
         // pass 1: radix 8, P = 1
         vdft<8>(v);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) sc[9 * t + q] = v[q];          // phys(8t + q) = 9t + q
+        for (int q = 0; q < 8; ++q) ADN_XWR(sc + xidx<M, 1>(8 * t + q), v[q]);
         wave_lds_fence();
-        wave_pass<M, R2, 8>(sc, tw2, t, v);
-        if constexpr (R3 > 1) wave_pass<M, R3, 8 * R2>(sc, tw3, t, v);
+        wave_pass<M, R2, 8, 1, (R3 > 1 ? 2 : 3)>(sc, tw2, t, v);
+        if constexpr (R3 > 1) wave_pass<M, R3, 8 * R2, 2, 3>(sc, tw3, t, v);
 
         // ---- real-FFT post-processing + magnitude into the [bin][frame] image ----
         float *mg = s_mag + fcol;
+        v2f pa[4], pb[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {          // all reads first: the volatile views keep program order
+            const int k = t + b * TPF;
+            pa[b] = ADN_XRD(sc + xidx<M, 3>(k));
+            pb[b] = ADN_XRD(sc + xidx<M, 3>((M - k) & (M - 1)));   // k = 0 pairs with itself
+        }
+        const v2f zh = 2.0f * ADN_XRD(sc + xidx<M, 3>(M / 2));
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const int k = t + b * TPF;
-            const v2f A = sc[phys(k)], Bc = sc[phys((M - k) & (M - 1))];   // k = 0 pairs with itself
+            const v2f A = pa[b], Bc = pb[b];
             const v2f Bz = {Bc.x, -Bc.y};
-            const v2f ev = 0.5f * (A + Bz), d = 0.5f * (A - Bz);
+            const v2f ev = A + Bz, d = A - Bz;                  // the 1/2 of Ev/Od is folded into the window
             const v2f wo = vmul(twp[b], vnegi(d));
             const v2f xa = ev + wo, xb = ev - wo;
             // k = 0: ev = (Re z0, 0), wo = (Im z0, 0)  ->  |xa| = |X[0]|, |xb| = |X[M]|  (same formulas)
             mg[k * MAGSTR] = __builtin_amdgcn_sqrtf(xa.x * xa.x + xa.y * xa.y);
             mg[(M - k) * MAGSTR] = __builtin_amdgcn_sqrtf(xb.x * xb.x + xb.y * xb.y);
         }
-        if (t == 0) {
-            const v2f zh = sc[phys(M / 2)];
-            mg[(M / 2) * MAGSTR] = __builtin_amdgcn_sqrtf(zh.x * zh.x + zh.y * zh.y);
-        }
+        if (t == 0) mg[(M / 2) * MAGSTR] = __builtin_amdgcn_sqrtf(zh.x * zh.x + zh.y * zh.y);
         wave_lds_fence();     // the slot's exchange image is reused by its next frame
 
         if (fi == FPS - 1) {
-            // ---- group complete: store with lanes along the frame axis; thread = (frame column, bin row) ----
+            // ---- group complete: store with lanes along the frame axis; thread = (frame column, bin row).
+            // Addresses are (uniform row-block base, computed on the scalar unit) + (per-thread constant offset):
+            // no per-element vector address arithmetic.  With 16 frame columns a 32-lane LDS read group spans two
+            // image rows; rows 16 apart sit 16 banks apart (MAGSTR = 17), so the pairing below is conflict-free.
             __syncthreads();
             constexpr int ROWS = NT / FPB;
-            const int fr = tid % FPB, k0 = tid / FPB;
+            const int fr = tid % FPB, rid = tid / FPB;
             const long fglob = (long)g * FPB + fr;
-            if (fglob < n_frames && !((ablate & 2) && k0 > 0)) {   // ablate&2: timing experiment, one row only
-                float *op = oclip + (long)k0 * n_frames + fglob;
-                const float *mp = s_mag + k0 * MAGSTR + fr;
-                const long ostep = (long)ROWS * n_frames;
+            float *gbase = oclip + (long)g * FPB;                      // wave-uniform
+            if constexpr (FPB == 16 && ROWS >= 2 && ROWS <= 32) {
+                constexpr int HALF = ROWS / 2, SUB = 16 / HALF, NBLK = (M + 1 + 31) / 32;
+                const int krow0 = (rid >> 1) + 16 * (rid & 1);
+                const unsigned voff = (unsigned)krow0 * (unsigned)n_frames + (unsigned)fr;
+                const float *mp0 = s_mag + krow0 * MAGSTR + fr;
+                if (fglob < n_frames) {
+#pragma unroll
+                    for (int blk = 0; blk < NBLK; ++blk)
+#pragma unroll
+                        for (int j = 0; j < SUB; ++j) {
+                            const int kk = 32 * blk + HALF * j;         // compile-time part of the row index
+                            if ((ablate & 2) && kk > 0) break;          // timing experiment: one row block only
+                            if (kk + 31 <= M || kk + krow0 <= M)
+                                (gbase + (long)kk * n_frames)[voff] = mp0[kk * MAGSTR];
+                        }
+                }
+            } else {
+                if (fglob < n_frames && !((ablate & 2) && rid > 0)) {
+                    float *op = oclip + (long)rid * n_frames + fglob;
+                    const float *mp = s_mag + rid * MAGSTR + fr;
+                    const long ostep = (long)ROWS * n_frames;
 #pragma unroll 4
-                for (int k = k0; k < ((ablate & 2) ? 1 : M + 1); k += ROWS) {
-                    *op = *mp;
-                    op += ostep;
-                    mp += ROWS * MAGSTR;
+                    for (int k = rid; k < ((ablate & 2) ? 1 : M + 1); k += ROWS) {
+                        *op = *mp;
+                        op += ostep;
+                        mp += ROWS * MAGSTR;
+                    }
                 }
             }
             __syncthreads();   // image is rewritten by the next group
@@ -507,7 +565,7 @@ __global__ __launch_bounds__(NW * 64) void stft_wave_kernel(const float *__restr
     }
 }
 
-template <int M, int NW, int FPB>
+template <int M, int NW, int FPB, int WPE = 3>
 hipError_t launch_wave(const float *audio, int n_clips, long L, int hop, int pad, long n_frames, const float *tables,
                        float *out, hipStream_t st, int gpb)
 {
@@ -518,8 +576,8 @@ hipError_t launch_wave(const float *audio, int n_clips, long L, int hop, int pad
     const long bpc = (groups + gpb - 1) / gpb;
     const long nwg = bpc * n_clips;
     if (nwg <= 0 || nwg > 0x7fffffffL) return hipErrorInvalidValue;
-    const size_t lds = (size_t)((((M + 1) * (FPB + 1) + 1) & ~1) + 2 * SLOTS * (M + M / 8)) * sizeof(float);
-    auto kern = stft_wave_kernel<M, NW, FPB>;
+    const size_t lds = (size_t)((((M + 1) * (FPB + 1) + 1) & ~1) + 2 * SLOTS * exch_size<M>()) * sizeof(float);
+    auto kern = stft_wave_kernel<M, NW, FPB, WPE>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -616,6 +674,7 @@ hipError_t launch_stft_mag(const float *audio, int n_clips, long L, int n_fft, i
                 if (variant == 1) return launch_wave<512, 8, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
                 if (variant == 3) return launch_wave<512, 8, 32>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
                 if (variant == 4) return launch_wave<512, 4, 32>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
+                if (variant == 5) return launch_wave<512, 8, 16, 4>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
                 return launch_wave<512, 4, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
             default: break;
         }

@@ -20,11 +20,12 @@ import torch
 from torch.utils.data import Dataset
 
 from . import _lib
+from .wav import read_wav
 
 
-def _list(data_dir: str, prefix: str):
+def _list(data_dir: str, prefix: str, suffix: str = ".npy"):
     return sorted(os.path.join(data_dir, f) for f in os.listdir(data_dir)
-                  if f.startswith(prefix) and f.endswith(".npy"))
+                  if f.startswith(prefix) and f.endswith(suffix))
 
 
 def fit_to(data: np.ndarray, target_size) -> np.ndarray:
@@ -80,3 +81,67 @@ def quantize_pad_on_device(spec: torch.Tensor, target_size) -> torch.Tensor:
         _lib.check(_lib.load().adn_quantize_pad(spec.data_ptr(), b, h, w, out.data_ptr(), H, W, stream),
                    "adn_quantize_pad")
     return out
+
+
+class WavToSpecDataset(Dataset):
+    """On-the-fly wav -> magnitude-spectrogram pairs: the dataset ``train.py`` imports
+    (``/root/reference/code/train.py:16,106-109``: ``WavToSpecDataset(data_dir=..., subset_fraction=...)``) but whose
+    module (``new_unet_data_loader``) is not part of the reference tree.  The contract is therefore assembled from
+    the reference pieces on either side of it:
+
+    * pairing as in ``SpectrogramDataset`` (``data_loader.py:17-31``): sorted ``clean*`` / ``noisy*`` files of one
+      folder, equal counts asserted, here with the ``.wav`` suffix;
+    * audio -> spectrogram as in ``audio_to_spectrogram`` (``create_test_dataset.py:35-41``): centred STFT,
+      n_fft 512 / hop 128 by default, magnitude;
+    * item format as in ``SpectrogramDataset.__getitem__`` (``data_loader.py:37-52``): fp32(fp16(.)), crop or
+      bottom/right zero-pad to ``target_size``, ``(noisy, clean)`` each ``(1, H, W)`` float32.
+
+    ``subset_fraction`` keeps the first ``max(1, int(n * fraction))`` pairs of the sorted list (deterministic).
+    The STFT, the quantisation and the crop/pad run on the device (``adn_stft_mag`` + ``adn_quantize_pad``);
+    items come back as host tensors like the reference's datasets, ``load_batch_to_device`` keeps whole batches
+    in HBM for the forward.  No resampling: ``sample_rate`` (if given) is checked against each file.
+    """
+
+    def __init__(self, data_dir, subset_fraction: float = 1.0, target_size=(256, 64), n_fft: int = 512,
+                 hop_length: int = 128, sample_rate=None, device="cuda"):
+        if not 0.0 < subset_fraction <= 1.0:
+            raise ValueError("subset_fraction must be in (0, 1]")
+        self.target_size = tuple(target_size)
+        self.n_fft, self.hop_length, self.sample_rate, self.device = n_fft, hop_length, sample_rate, device
+        clean = _list(data_dir, "clean", ".wav")
+        noisy = _list(data_dir, "noisy", ".wav")
+        print(f"Found {len(clean)} clean files and {len(noisy)} noisy files in {data_dir}")
+        assert len(clean) == len(noisy), f"Mismatch in {data_dir}"
+        pairs = list(zip(noisy, clean))
+        keep = max(1, int(len(pairs) * subset_fraction)) if pairs else 0
+        self.pairs = pairs[:keep]
+        print(f"Total pairs loaded: {len(self.pairs)}")
+
+    def __len__(self):
+        return len(self.pairs)
+
+    def _audio(self, path):
+        audio, rate = read_wav(path, mono=True)
+        if self.sample_rate is not None and rate != self.sample_rate:
+            raise ValueError(f"{path}: sample rate {rate} != expected {self.sample_rate} (no resampler in this build)")
+        return audio
+
+    def _spec_batch(self, audios):
+        """list of equally long 1-D float32 arrays -> (B, 1, H, W) float32 on the device."""
+        from .stft import stft_magnitude
+        a = torch.from_numpy(np.stack(audios)).to(self.device)
+        return quantize_pad_on_device(stft_magnitude(a, self.n_fft, self.hop_length, True), self.target_size)
+
+    def __getitem__(self, idx):
+        noisy_path, clean_path = self.pairs[idx]
+        noisy, clean = self._audio(noisy_path), self._audio(clean_path)
+        if len(noisy) == len(clean):
+            both = self._spec_batch([noisy, clean]).cpu()
+            return both[0], both[1]
+        return self._spec_batch([noisy]).cpu()[0], self._spec_batch([clean]).cpu()[0]
+
+    def load_batch_to_device(self, indices):
+        """(noisy, clean) batches ``(B, 1, H, W)`` on the device; clips of one call must have one length."""
+        noisy = [self._audio(self.pairs[i][0]) for i in indices]
+        clean = [self._audio(self.pairs[i][1]) for i in indices]
+        return self._spec_batch(noisy), self._spec_batch(clean)

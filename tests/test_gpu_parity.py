@@ -364,3 +364,34 @@ def test_fp16_path_batch256(dev, weights_np):
         for i in (0, 255):
             ref = m(x[i:i + 1].clone())
             assert float((y[i:i + 1] - ref).abs().max() / ref.abs().max()) <= 1e-2
+
+
+@pytest.mark.gpu
+def test_wav_to_spec_dataset_matches_oracle(dev, tmp_path):
+    """On-the-fly wav dataset (train.py:106-109): item = fp32(fp16(|STFT|)) cropped/padded, vs the CPU oracle."""
+    from audiodenoiser_amd.data_loader import WavToSpecDataset
+    import oracle
+    from audiodenoiser_amd.wav import read_wav, write_wav
+    rng = np.random.default_rng(11)
+    lengths = [8000, 8000, 6000, 24000]
+    for i, n in enumerate(lengths):
+        clean = (rng.uniform(-1, 1, n) * 0.3).astype(np.float32)
+        noisy = (clean + rng.normal(0, 0.05, n)).astype(np.float32)
+        write_wav(str(tmp_path / f"clean_{i}.wav"), clean, 8000, "FLOAT" if i % 2 else "PCM_16")
+        write_wav(str(tmp_path / f"noisy_{i}.wav"), noisy, 8000, "FLOAT" if i % 2 else "PCM_16")
+    ds = WavToSpecDataset(str(tmp_path), target_size=(256, 64), sample_rate=8000, device=dev)
+    assert len(ds) == 4
+    for i in range(4):
+        noisy, clean = ds[i]
+        assert noisy.shape == clean.shape == (1, 256, 64) and noisy.dtype == torch.float32 and not noisy.is_cuda
+        for got, name in ((noisy, "noisy"), (clean, "clean")):
+            audio, _ = read_wav(str(tmp_path / f"{name}_{i}.wav"))
+            ref = oracle.quantize_pad(oracle.stft_mag(audio, 512, 128, True), (256, 64))
+            # fp16 rounding of values that differ by 1e-6 relative may flip one fp16 ulp (2^-11 relative)
+            assert np.max(np.abs(got.numpy()[0] - ref)) <= 2.0 ** -10 * np.max(np.abs(ref))
+            assert _rel(got.numpy()[0], ref) <= 1e-3
+    nb, cb = ds.load_batch_to_device([0, 1])
+    assert nb.shape == (2, 1, 256, 64) and nb.is_cuda
+    assert torch.equal(nb[0].cpu(), ds[0][0]) and torch.equal(cb[1].cpu(), ds[1][1])
+    with pytest.raises(ValueError):
+        WavToSpecDataset(str(tmp_path), sample_rate=16000, device=dev)[0]

@@ -180,3 +180,67 @@ def test_two_rank_gloo_gather(weights_np):
         assert allv.shape == (4,)
         assert np.array_equal(allv, ref)      # same arithmetic per clip -> identical, in rank order
         assert tmax == 2.0
+
+
+def test_wav_reader_formats(tmp_path):
+    """PCM16 (checked against the stdlib reader), float32, stereo mix-down, extensible header, odd chunk padding."""
+    import struct
+    import wave
+    from audiodenoiser_amd.wav import read_wav, write_wav
+    rng = np.random.default_rng(3)
+    a = (rng.uniform(-1, 1, 1001) * 0.9).astype(np.float32)
+    p16 = str(tmp_path / "a16.wav")
+    write_wav(p16, a, 8000, "PCM_16")
+    with wave.open(p16, "rb") as w:
+        assert (w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()) == (1, 2, 8000, 1001)
+        ref = np.frombuffer(w.readframes(1001), dtype="<i2").astype(np.float32) / 32768.0
+    got, rate = read_wav(p16)
+    assert rate == 8000 and got.dtype == np.float32 and np.array_equal(got, ref)
+    assert np.max(np.abs(got - a)) <= 0.5 / 32768 + 1e-7
+    pf = str(tmp_path / "af.wav")
+    write_wav(pf, a, 44100, "FLOAT")
+    got, rate = read_wav(pf)
+    assert rate == 44100 and np.array_equal(got, a)
+    st = np.stack([a, -0.5 * a], axis=1)
+    ps = str(tmp_path / "st.wav")
+    write_wav(ps, st, 8000, "FLOAT")
+    mono, _ = read_wav(ps)
+    assert np.allclose(mono, 0.25 * a, atol=1e-7)
+    both, _ = read_wav(ps, mono=False)
+    assert both.shape == (1001, 2) and np.array_equal(both, st)
+    # WAVE_FORMAT_EXTENSIBLE header + a LIST chunk of odd size before the data + 8-bit PCM
+    pcm8 = np.array([0, 64, 128, 192, 255], dtype=np.uint8)
+    fmt = struct.pack("<HHIIHH", 0xFFFE, 1, 8000, 8000, 1, 8) + struct.pack("<HHI", 22, 8, 4) + \
+        struct.pack("<H", 1) + b"\x00\x00\x00\x00\x10\x00\x80\x00\x00\xaa\x00\x38\x9b\x71"
+    body = b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt + b"LIST" + struct.pack("<I", 3) + b"abc\x00" + \
+        b"data" + struct.pack("<I", 5) + pcm8.tobytes() + b"\x00"
+    pe = tmp_path / "ext.wav"
+    pe.write_bytes(b"RIFF" + struct.pack("<I", len(body)) + body)
+    got, rate = read_wav(str(pe))
+    assert rate == 8000 and np.array_equal(got, (pcm8.astype(np.float32) - 128) / 128)
+    bad = tmp_path / "bad.wav"
+    bad.write_bytes(b"RIFX" + b"\x00" * 40)
+    with pytest.raises(ValueError):
+        read_wav(str(bad))
+
+
+def test_wav_dataset_discovery_and_subset(tmp_path, capsys):
+    from audiodenoiser_amd.data_loader import WavToSpecDataset
+    from audiodenoiser_amd.wav import write_wav
+    for i in range(5):
+        write_wav(str(tmp_path / f"clean_{i}.wav"), np.zeros(800, np.float32), 8000)
+        write_wav(str(tmp_path / f"noisy_{i}.wav"), np.zeros(800, np.float32), 8000)
+    (tmp_path / "clean_notes.txt").write_text("ignored")
+    ds = WavToSpecDataset(str(tmp_path), subset_fraction=0.5)
+    out = capsys.readouterr().out
+    assert "Found 5 clean files and 5 noisy files" in out and "Total pairs loaded: 2" in out
+    assert len(ds) == 2
+    assert [os.path.basename(n) for n, _ in ds.pairs] == ["noisy_0.wav", "noisy_1.wav"]
+    assert [os.path.basename(c) for _, c in ds.pairs] == ["clean_0.wav", "clean_1.wav"]
+    assert len(WavToSpecDataset(str(tmp_path))) == 5
+    assert len(WavToSpecDataset(str(tmp_path), subset_fraction=0.01)) == 1
+    with pytest.raises(ValueError):
+        WavToSpecDataset(str(tmp_path), subset_fraction=0.0)
+    os.remove(tmp_path / "noisy_4.wav")
+    with pytest.raises(AssertionError):
+        WavToSpecDataset(str(tmp_path))
