@@ -54,10 +54,18 @@ def load() -> ctypes.CDLL:
         L.adn_per_clip_l1.argtypes = [vp, vp, ci, cl, vp, vp]
         L.adn_perceptual_loss_workspace_bytes.argtypes = [ci, ci, ci, ctypes.POINTER(sz)]
         L.adn_perceptual_loss.argtypes = [vp, vp, ci, ci, ci, vp, sz, vp, vp]
+        L.adn_istft_length.argtypes = [ci, ci, ctypes.POINTER(cl)]
+        L.adn_griffin_lim_workspace_bytes.argtypes = [ci, ci, ci, ctypes.POINTER(sz)]
+        L.adn_griffin_lim.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, vp, sz, vp, vp]
+        L.adn_stft_complex.argtypes = [vp, ci, cl, ci, ci, vp, vp]
+        L.adn_istft_workspace_bytes.argtypes = [ci, ci, ci, ctypes.POINTER(sz)]
+        L.adn_istft.argtypes = [vp, ci, ci, ci, ci, vp, sz, vp, vp]
         for name in ("adn_device_count", "adn_unet_create", "adn_unet_create_ex", "adn_unet_destroy", "adn_unet_workspace_bytes",
                      "adn_unet_forward", "adn_unet_forward_taps", "adn_unet_set_timing", "adn_unet_get_timing",
                      "adn_stft_n_frames", "adn_stft_mag", "adn_quantize_pad", "adn_per_clip_l1",
-                     "adn_perceptual_loss_workspace_bytes", "adn_perceptual_loss"):
+                     "adn_perceptual_loss_workspace_bytes", "adn_perceptual_loss", "adn_istft_length",
+                     "adn_griffin_lim_workspace_bytes", "adn_griffin_lim", "adn_stft_complex",
+                     "adn_istft_workspace_bytes", "adn_istft"):
             getattr(L, name).restype = ci
         _lib = L
         return L
@@ -74,4 +82,6 @@ EXPORTED_SYMBOLS = (
     "adn_unet_workspace_bytes", "adn_unet_forward", "adn_unet_forward_taps", "adn_unet_set_timing",
     "adn_unet_get_timing", "adn_stft_n_frames", "adn_stft_mag",
     "adn_quantize_pad", "adn_per_clip_l1", "adn_perceptual_loss_workspace_bytes", "adn_perceptual_loss",
+    "adn_istft_length", "adn_griffin_lim_workspace_bytes", "adn_griffin_lim", "adn_stft_complex",
+    "adn_istft_workspace_bytes", "adn_istft",
 )

@@ -598,4 +598,79 @@ int adn_perceptual_loss(const float *pred, const float *target, int n_clips, int
     return ADN_OK;
 }
 
+/* ---- inverse STFT / Griffin-Lim (test.py:29-48) -------------------------------------------------------------- */
+static bool gl_size_ok(int n_fft) { return n_fft >= 64 && n_fft <= 4096 && (n_fft & (n_fft - 1)) == 0; }
+
+int adn_istft_length(int n_frames, int hop, long *length)
+{
+    if (!length || n_frames < 1 || hop < 1) return fail(ADN_ERR_INVALID, "adn_istft_length: need n_frames, hop >= 1");
+    *length = (long)hop * (n_frames - 1);
+    return ADN_OK;
+}
+
+int adn_stft_complex(const float *audio, int n_clips, long length, int n_fft, int hop, float *spec_out, void *stream)
+{
+    if (!audio || !spec_out) return fail(ADN_ERR_INVALID, "adn_stft_complex: null pointer");
+    if (!gl_size_ok(n_fft)) return fail(ADN_ERR_INVALID, "adn_stft_complex: n_fft must be a power of two in [64, 4096]");
+    if (n_clips < 1 || hop < 1 || length < 1 || length >= (1L << 30)) return fail(ADN_ERR_INVALID, "adn_stft_complex: bad sizes");
+    const long T = 1 + length / hop;
+    if (T > 0x7fffffffL) return fail(ADN_ERR_INVALID, "adn_stft_complex: too many frames");
+    ADN_HIP(adn::launch_stft_complex(audio, n_clips, length, n_fft, hop, (int)T, spec_out, static_cast<hipStream_t>(stream)));
+    return ADN_OK;
+}
+
+int adn_istft_workspace_bytes(int n_clips, int n_frames, int n_fft, size_t *bytes)
+{
+    if (!bytes || n_clips < 1 || n_frames < 2 || !gl_size_ok(n_fft)) return fail(ADN_ERR_INVALID, "adn_istft_workspace_bytes: bad sizes");
+    *bytes = (size_t)n_clips * n_frames * n_fft * sizeof(float);
+    return ADN_OK;
+}
+
+int adn_istft(const float *spec, int n_clips, int n_frames, int n_fft, int hop, void *workspace, size_t workspace_bytes,
+              float *audio_out, void *stream)
+{
+    if (!spec || !audio_out) return fail(ADN_ERR_INVALID, "adn_istft: null pointer");
+    if (!gl_size_ok(n_fft) || n_clips < 1 || n_frames < 2 || hop < 1 || hop > n_fft)
+        return fail(ADN_ERR_INVALID, "adn_istft: need power-of-two n_fft in [64,4096], n_frames >= 2, 1 <= hop <= n_fft");
+    const size_t need = (size_t)n_clips * n_frames * n_fft * sizeof(float);
+    if (!workspace || workspace_bytes < need) return fail(ADN_ERR_WORKSPACE, "adn_istft: workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ADN_HIP(adn::launch_istft_frames(spec, n_clips, n_frames, n_fft, static_cast<float *>(workspace), st));
+    ADN_HIP(adn::launch_istft_ola(static_cast<const float *>(workspace), n_clips, n_frames, n_fft, hop, audio_out, st));
+    return ADN_OK;
+}
+
+int adn_griffin_lim_workspace_bytes(int n_clips, int n_bins, int n_frames, size_t *bytes)
+{
+    if (!bytes || n_clips < 1 || n_bins < 33 || n_frames < 2) return fail(ADN_ERR_INVALID, "adn_griffin_lim_workspace_bytes: bad sizes");
+    const size_t n_fft = 2 * (size_t)(n_bins - 1);
+    *bytes = (size_t)n_clips * n_frames * ((size_t)n_bins * 2 + n_fft) * sizeof(float);
+    return ADN_OK;
+}
+
+int adn_griffin_lim(const float *magnitude, const float *rnd, int n_clips, int n_bins, int n_frames, int n_fft, int hop,
+                    int iterations, void *workspace, size_t workspace_bytes, float *audio_out, void *stream)
+{
+    if (!magnitude || !rnd || !audio_out) return fail(ADN_ERR_INVALID, "adn_griffin_lim: null pointer");
+    if (!gl_size_ok(n_fft) || n_bins != n_fft / 2 + 1)
+        return fail(ADN_ERR_INVALID, "adn_griffin_lim: need power-of-two n_fft in [64,4096] and n_bins = n_fft/2+1");
+    if (n_clips < 1 || n_frames < 2 || hop < 1 || hop > n_fft || iterations < 0)
+        return fail(ADN_ERR_INVALID, "adn_griffin_lim: need n_clips >= 1, n_frames >= 2, 1 <= hop <= n_fft, iterations >= 0");
+    size_t need = 0;
+    adn_griffin_lim_workspace_bytes(n_clips, n_bins, n_frames, &need);
+    if (!workspace || workspace_bytes < need) return fail(ADN_ERR_WORKSPACE, "adn_griffin_lim: workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float *spec = static_cast<float *>(workspace);
+    float *buf = spec + (size_t)n_clips * n_frames * n_bins * 2;
+    const long len = (long)hop * (n_frames - 1);
+    ADN_HIP(adn::launch_gl_polar(magnitude, rnd, n_clips, n_bins, n_frames, spec, st));
+    for (int it = 0; it <= iterations; ++it) {
+        ADN_HIP(adn::launch_istft_frames(spec, n_clips, n_frames, n_fft, buf, st));
+        ADN_HIP(adn::launch_istft_ola(buf, n_clips, n_frames, n_fft, hop, audio_out, st));
+        if (it < iterations)   // test.py:41-46: S = |Z| exp(i angle Z) with Z = stft(audio) -- Z itself up to rounding
+            ADN_HIP(adn::launch_stft_complex(audio_out, n_clips, len, n_fft, hop, n_frames, spec, st));
+    }
+    return ADN_OK;
+}
+
 }  // extern "C"

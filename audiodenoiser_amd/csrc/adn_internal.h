@@ -56,6 +56,13 @@ hipError_t launch_nhwc_to_nchw(const void *in, bool f16, float *out, int N, int 
 
 hipError_t launch_stft_mag(const float *audio, int n_clips, long L, int n_fft, int hop, int center,
                            long n_frames, float *out, hipStream_t st);
+hipError_t stft_tables(int n_fft, const float **out);
+// Griffin-Lim building blocks (gl_kernels.hip); complex spectrograms are frame-major [clip][frame][F] float2
+hipError_t launch_gl_polar(const float *mag, const float *rnd, int n_clips, int F, int T, void *spec, hipStream_t st);
+hipError_t launch_istft_frames(const void *spec, int n_clips, int T, int n_fft, float *buf, hipStream_t st);
+hipError_t launch_istft_ola(const float *buf, int n_clips, int T, int n_fft, int hop, float *audio, hipStream_t st);
+hipError_t launch_stft_complex(const float *audio, int n_clips, long L, int n_fft, int hop, int T, void *spec,
+                               hipStream_t st);
 hipError_t launch_quantize_pad(const float *in, int n, int h, int w, float *out, int H, int W, hipStream_t st);
 hipError_t launch_per_clip_l1(const float *a, const float *b, int n_clips, long elems, float *out, hipStream_t st);
 size_t perceptual_loss_workspace_floats(int n_clips, int F, int T);

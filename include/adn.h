@@ -113,6 +113,25 @@ int adn_perceptual_loss_workspace_bytes(int n_clips, int F, int T, size_t *bytes
 int adn_perceptual_loss(const float *pred, const float *target, int n_clips, int F, int T, void *workspace,
                         size_t workspace_bytes, float *out, void *stream);
 
+/* ---- inverse STFT and Griffin-Lim ----------------------------------------------------------------------------
+ * Replaces griffin_lim_reconstruction (/root/reference/code/test.py:29-48): librosa.istft + librosa.stft iterated
+ * from a random-phase start (librosa 0.10 defaults: n_fft = 2*(n_bins-1), periodic Hann, center=True, zero pad,
+ * istft length = hop*(n_frames-1), window sum-of-squares normalisation).  As in the reference the target magnitude is
+ * NOT re-imposed inside the loop.  `rnd` holds what np.random.rand(F, T) returned (uniform [0,1), as float32).
+ * magnitude, rnd: device (n_clips, n_bins, n_frames) fp32 [the reference's (F, T) layout]; audio_out: device
+ * (n_clips, hop*(n_frames-1)) fp32.  Complex spectrograms of the building blocks below are FRAME-major:
+ * (n_clips, n_frames, n_bins, 2) fp32. */
+int adn_istft_length(int n_frames, int hop, long *length);
+int adn_griffin_lim_workspace_bytes(int n_clips, int n_bins, int n_frames, size_t *bytes);
+int adn_griffin_lim(const float *magnitude, const float *rnd, int n_clips, int n_bins, int n_frames, int n_fft, int hop,
+                    int iterations, void *workspace, size_t workspace_bytes, float *audio_out, void *stream);
+/* librosa.stft(audio, n_fft, hop) complex result, centred: n_frames = 1 + length/hop (test.py:41-43). */
+int adn_stft_complex(const float *audio, int n_clips, long length, int n_fft, int hop, float *spec_out, void *stream);
+/* librosa.istft(spec, hop_length=hop) (test.py:40,48); workspace = n_clips*n_frames*n_fft floats. */
+int adn_istft_workspace_bytes(int n_clips, int n_frames, int n_fft, size_t *bytes);
+int adn_istft(const float *spec, int n_clips, int n_frames, int n_fft, int hop, void *workspace, size_t workspace_bytes,
+              float *audio_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -395,3 +395,54 @@ def test_wav_to_spec_dataset_matches_oracle(dev, tmp_path):
     assert torch.equal(nb[0].cpu(), ds[0][0]) and torch.equal(cb[1].cpu(), ds[1][1])
     with pytest.raises(ValueError):
         WavToSpecDataset(str(tmp_path), sample_rate=16000, device=dev)[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_fft,hop,nfr", [(512, 128, 188), (256, 64, 33), (1024, 256, 40), (512, 256, 21), (64, 16, 9)])
+def test_istft_and_complex_stft_match_oracle(dev, n_fft, hop, nfr):
+    from oracle import griffin_lim_numpy as gl
+    from audiodenoiser_amd.griffin_lim import istft, stft_complex
+    rng = np.random.default_rng(n_fft + nfr)
+    spec = (rng.normal(size=(2, n_fft // 2 + 1, nfr)) + 1j * rng.normal(size=(2, n_fft // 2 + 1, nfr))).astype(np.complex64)
+    fm = torch.from_numpy(np.ascontiguousarray(spec.transpose(0, 2, 1))).to(dev)        # frame-major
+    got = istft(fm, hop).cpu().numpy()
+    for c in range(2):
+        ref = gl.istft(spec[c], hop)
+        assert got[c].shape == ref.shape
+        assert np.max(np.abs(got[c] - ref)) <= TOL * np.max(np.abs(ref))
+    audio = rng.uniform(-1, 1, (2, hop * (nfr - 1))).astype(np.float32)
+    z = stft_complex(torch.from_numpy(audio).to(dev), n_fft, hop).cpu().numpy()
+    for c in range(2):
+        ref = gl.stft_complex(audio[c], n_fft, hop, True).T
+        assert z[c].shape == ref.shape
+        assert np.max(np.abs(z[c] - ref)) <= TOL * np.max(np.abs(ref))
+    # round trip on the device: Hann at hop <= n_fft/2 reconstructs exactly
+    back = istft(stft_complex(torch.from_numpy(audio).to(dev), n_fft, hop), hop).cpu().numpy()
+    assert np.max(np.abs(back - audio)) <= 1e-5
+
+
+@pytest.mark.gpu
+def test_griffin_lim_matches_oracle_and_reference_shapes(dev):
+    """test.py:29-48 with the reference's sizes (257 x 188, n_fft 512, hop 128, 50 iterations)."""
+    from oracle import griffin_lim_numpy as gl
+    from audiodenoiser_amd.griffin_lim import griffin_lim_reconstruction
+    rng = np.random.default_rng(8)
+    clip = rng.uniform(-1, 1, 24000).astype(np.float32)
+    mag = np.abs(gl.stft_complex(clip, 512, 128, True)).astype(np.float32)            # (257, 188)
+    rand = rng.random(mag.shape)
+    for iters in (0, 2, 50):
+        got = griffin_lim_reconstruction(mag, 512, 128, iterations=iters, rand=rand)
+        assert isinstance(got, np.ndarray) and got.shape == (128 * 187,) and got.dtype == np.float32
+        ref = gl.griffin_lim(mag, 512, 128, min(iters, 2), rand)     # the loop is a fixed point (see oracle test)
+        assert np.max(np.abs(got - ref)) <= TOL * np.max(np.abs(ref))
+    # batch + tensor in / tensor out, unseeded start phase like the reference
+    mags = torch.from_numpy(np.stack([mag, 0.5 * mag])).to(dev)
+    out = griffin_lim_reconstruction(mags, 512, 128, iterations=3)
+    assert out.is_cuda and out.shape == (2, 128 * 187) and torch.isfinite(out).all()
+    # statistical check for the random start: projecting a random-phase spectrogram onto the consistent ones keeps
+    # about hop/n_fft = 1/4 of its energy (4x redundant frames)
+    z = np.abs(gl.stft_complex(out[0].cpu().numpy(), 512, 128, True))
+    assert 0.15 < float(np.sum(z ** 2) / np.sum(mag ** 2)) < 0.4
+    from audiodenoiser_amd._lib import AdnError
+    with pytest.raises(AdnError):
+        griffin_lim_reconstruction(mag[:200], 512, 128)

@@ -76,3 +76,35 @@ def test_known_answers():
 def test_too_short_raises():
     with pytest.raises(ValueError):
         oracle.stft_mag(np.zeros(100, np.float32), 512, 128, False)
+
+
+def test_istft_oracle_matches_torch_istft_and_round_trip():
+    """oracle/griffin_lim_numpy.py restates librosa.istft; torch.istft follows the same semantics (secondary oracle)."""
+    import torch
+    from oracle import griffin_lim_numpy as gl
+    rng = np.random.default_rng(5)
+    for n_fft, hop, nfr in ((512, 128, 188), (256, 64, 33), (1024, 256, 40), (512, 256, 21)):
+        spec = (rng.normal(size=(n_fft // 2 + 1, nfr)) + 1j * rng.normal(size=(n_fft // 2 + 1, nfr))).astype(np.complex64)
+        ours = gl.istft(spec, hop)
+        ref = torch.istft(torch.from_numpy(spec), n_fft, hop, n_fft, window=torch.hann_window(n_fft, periodic=True),
+                          center=True).numpy()
+        assert ours.shape == ref.shape == (gl.istft_length(nfr, hop),)
+        assert np.max(np.abs(ours - ref)) <= 2e-6 * np.max(np.abs(ref))
+    a = rng.uniform(-1, 1, 24000).astype(np.float32)
+    z = gl.stft_complex(a, 512, 128, True)
+    assert z.shape == (257, 188) and z.dtype == np.complex64
+    assert np.array_equal(np.abs(z).astype(np.float32), __import__("oracle").stft_numpy.stft_mag(a, 512, 128, True))
+    back = gl.istft(z, 128)
+    assert np.max(np.abs(back - a[:len(back)])) <= 1e-6          # Hann, hop = n_fft/4: perfect reconstruction
+
+
+def test_griffin_lim_oracle_loop_is_a_fixed_point():
+    """test.py:39-46 never re-imposes the magnitude: every pass after the first istft is stft o istft = identity."""
+    from oracle import griffin_lim_numpy as gl
+    rng = np.random.default_rng(6)
+    mag = np.abs(rng.normal(size=(257, 60))).astype(np.float32)
+    rand = rng.random((257, 60))
+    y0 = gl.griffin_lim(mag, 512, 128, 0, rand)
+    y3 = gl.griffin_lim(mag, 512, 128, 3, rand)
+    assert y0.shape == (128 * 59,)
+    assert np.max(np.abs(y0 - y3)) <= 5e-6 * np.max(np.abs(y0))
