@@ -38,7 +38,6 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int TW = 16;       // tile width (pixels)
-constexpr int NTHREADS = 256;
 
 template <typename T> struct Elem;
 template <> struct Elem<float> { static constexpr int EPV = 4; };       // elements per 16-byte vector
@@ -54,8 +53,9 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg)
 }
 
 template <typename T, int TH, int BN, int WM, int WN, int TAPS, int KG, int EPI>
-__global__ __launch_bounds__(NTHREADS, 2) void conv_mfma(const ConvArgs p)
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 4) void conv_mfma(const ConvArgs p)
 {
+    constexpr int NTHREADS = 64 * WM * WN;      // 4 waves (fp32 tiles) or 8 waves (the larger fp16 tiles)
     constexpr int EPV = Elem<T>::EPV;
     constexpr int HALO = (TAPS == 9) ? 1 : 0;
     constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma(const ConvArgs p)
     constexpr int B_ROUNDS = (B_ITEMS + NTHREADS - 1) / NTHREADS;
     constexpr int MB = TH * TW / 32 / WM;       // 32-row MFMA blocks per wave
     constexpr int NB = BN / 32 / WN;            // 32-column MFMA blocks per wave
-    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves per workgroup");
     static_assert(MB >= 1 && NB >= 1, "tile too small");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -387,20 +387,33 @@ hipError_t launch_cfg(const ConvArgs &a, hipStream_t st)
     constexpr size_t lds = (size_t)(PH * PW * (8 * KG + 4) + TAPS * KG * 2 * BN * 4) * sizeof(float);
     const long nwg = (long)a.N * a.tilesY * a.tilesX * a.nct;
     if (nwg <= 0 || nwg > 0x7fffffffL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((conv_mfma<T, TH, BN, WM, WN, TAPS, KG, EPI>), dim3((unsigned)nwg), dim3(NTHREADS), lds, st, a);
+    hipLaunchKernelGGL((conv_mfma<T, TH, BN, WM, WN, TAPS, KG, EPI>), dim3((unsigned)nwg), dim3(64 * WM * WN), lds, st, a);
     return hipGetLastError();
 }
 
 template <typename T>
 hipError_t launch_conv_mfma_t(ConvKind kind, const ConvArgs &a, hipStream_t st)
 {
-    if (kind == CONVT2X2) return launch_cfg<T, 8, 128, 2, 2, 1, 4, CONVT2X2>(a, st);
-    if (a.Cout == 64) {
-        if (kind == CONV3X3_RELU_POOL) return launch_cfg<T, 16, 64, 4, 1, 9, 1, CONV3X3_RELU_POOL>(a, st);
-        return launch_cfg<T, 16, 64, 4, 1, 9, 1, CONV3X3_RELU>(a, st);
+    if constexpr (sizeof(T) == 2) {
+        // fp16: the matrix cores are 16x faster than for fp32 while the CU's ingest path is not, so the kernel is
+        // bound by the bytes staged per FLOP; 8-wave workgroups on 2x larger pixel tiles amortise the weight slab
+        // over twice the pixels (same accumulator count per wave).
+        if (kind == CONVT2X2) return launch_cfg<T, 16, 128, 4, 2, 1, 4, CONVT2X2>(a, st);
+        if (a.Cout == 64) {
+            if (kind == CONV3X3_RELU_POOL) return launch_cfg<T, 32, 64, 8, 1, 9, 1, CONV3X3_RELU_POOL>(a, st);
+            return launch_cfg<T, 32, 64, 8, 1, 9, 1, CONV3X3_RELU>(a, st);
+        }
+        if (kind == CONV3X3_RELU_POOL) return launch_cfg<T, 16, 128, 4, 2, 9, 1, CONV3X3_RELU_POOL>(a, st);
+        return launch_cfg<T, 16, 128, 4, 2, 9, 1, CONV3X3_RELU>(a, st);
+    } else {
+        if (kind == CONVT2X2) return launch_cfg<T, 8, 128, 2, 2, 1, 4, CONVT2X2>(a, st);
+        if (a.Cout == 64) {
+            if (kind == CONV3X3_RELU_POOL) return launch_cfg<T, 16, 64, 4, 1, 9, 1, CONV3X3_RELU_POOL>(a, st);
+            return launch_cfg<T, 16, 64, 4, 1, 9, 1, CONV3X3_RELU>(a, st);
+        }
+        if (kind == CONV3X3_RELU_POOL) return launch_cfg<T, 8, 128, 2, 2, 9, 1, CONV3X3_RELU_POOL>(a, st);
+        return launch_cfg<T, 8, 128, 2, 2, 9, 1, CONV3X3_RELU>(a, st);
     }
-    if (kind == CONV3X3_RELU_POOL) return launch_cfg<T, 8, 128, 2, 2, 9, 1, CONV3X3_RELU_POOL>(a, st);
-    return launch_cfg<T, 8, 128, 2, 2, 9, 1, CONV3X3_RELU>(a, st);
 }
 
 }  // namespace
@@ -409,9 +422,10 @@ hipError_t launch_conv_mfma_t(ConvKind kind, const ConvArgs &a, hipStream_t st)
 ConvGeom conv_geom(ConvKind kind, int Cout, bool f16)
 {
     const int cpg = f16 ? 16 : 8;                // channels per k-group
-    if (kind == CONVT2X2) return ConvGeom{8, 128, 4 * cpg};
-    if (Cout == 64) return ConvGeom{16, 64, cpg};
-    return ConvGeom{8, 128, cpg};
+    const int th = f16 ? 2 : 1;                  // fp16 tiles are twice as tall (8-wave workgroups)
+    if (kind == CONVT2X2) return ConvGeom{8 * th, 128, 4 * cpg};
+    if (Cout == 64) return ConvGeom{16 * th, 64, cpg};
+    return ConvGeom{8 * th, 128, cpg};
 }
 
 hipError_t launch_conv_mfma(ConvKind kind, const ConvArgs &a, bool f16, hipStream_t st)

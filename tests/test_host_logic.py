@@ -244,3 +244,17 @@ def test_wav_dataset_discovery_and_subset(tmp_path, capsys):
     os.remove(tmp_path / "noisy_4.wav")
     with pytest.raises(AssertionError):
         WavToSpecDataset(str(tmp_path))
+
+
+def test_compat_modules_resolve_reference_import_names():
+    """PYTHONPATH=compat: the reference's `from model import UNet` etc. pick up the MI355X mirror."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    want = {"model": ["UNet"], "data_loader": ["SpectrogramDataset"], "loss": ["CombinedPerceptualLoss"],
+            "new_unet_data_loader": ["WavToSpecDataset"]}
+    for mod, names in want.items():
+        spec = importlib.util.spec_from_file_location(f"_compat_{mod}", os.path.join(root, "compat", f"{mod}.py"))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        for n in names:
+            assert getattr(m, n).__module__.startswith("audiodenoiser_amd.")
