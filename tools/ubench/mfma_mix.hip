@@ -1,0 +1,117 @@
+// What keeps a 2-waves-per-SIMD fp32-MFMA loop below 100 %?  Synthetic chunk loop with the instruction mix of the
+// Winograd kernel: per chunk and wave 64 v_mfma_f32_16x16x4_f32 on 32 accumulators, optionally preceded by VALU
+// work (packed or scalar adds), LDS fragment reads and a workgroup barrier.  256-thread workgroups, 2 per CU.
+// Build: hipcc --offload-arch=gfx950 -O3 -o mfma_mix mfma_mix.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// MODE bits: 1 = 32 v_pk_add_f32 per chunk, 2 = 64 v_add_f32 per chunk, 4 = s_barrier per chunk,
+//            8 = 32 ds_read_b64 per chunk feeding the B operands, 16 = VALU interleaved between MFMA groups
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void k(float *out, int nchunk)
+{
+    extern __shared__ float smem[];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 4096; i += 256) smem[i] = (float)(i & 7) * 0.125f;
+    __syncthreads();
+    f32x4 acc[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x2 V[16], B[32];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) V[i] = f32x2{(float)(tid & 3) + i, 1.f};
+#pragma unroll
+    for (int i = 0; i < 32; ++i) B[i] = f32x2{0.5f, 0.25f * i};
+    const f32x2 inc = {0.001f, 0.002f};
+    for (int c = 0; c < nchunk; ++c) {
+        if constexpr ((MODE & 1) && !(MODE & 16)) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(V[i]) : "v"(inc));
+        }
+        if constexpr ((MODE & 2) && !(MODE & 16)) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    asm volatile("v_add_f32 %0, %0, %1" : "+v"(V[i].x) : "v"(inc.x));
+                    asm volatile("v_add_f32 %0, %0, %1" : "+v"(V[i].y) : "v"(inc.y));
+                }
+        }
+        if constexpr (MODE & 8) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i)
+                B[i] = *(const volatile f32x2 __attribute__((address_space(3))) *)(smem + ((tid & 63) * 2 + i * 128) % 4096);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if constexpr (MODE & 16) {       // the chunk's VALU work spread over the four MFMA groups
+                if constexpr (MODE & 1) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(V[(4 * g + i) & 15]) : "v"(inc));
+                }
+                if constexpr (MODE & 2) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        asm volatile("v_add_f32 %0, %0, %1" : "+v"(V[(4 * g + i) & 15].x) : "v"(inc.x));
+                        asm volatile("v_add_f32 %0, %0, %1" : "+v"(V[(4 * g + i) & 15].y) : "v"(inc.y));
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    acc[16 * j + 4 * g + s] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[4 * g + s].x, B[16 * j + 4 * g + s].x, acc[16 * j + 4 * g + s], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    acc[16 * j + 4 * g + s] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[4 * g + s].y, B[16 * j + 4 * g + s].y, acc[16 * j + 4 * g + s], 0, 0, 0);
+        }
+        if constexpr (MODE & 4) __syncthreads();
+    }
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 32; ++i) s += acc[i];
+    out[blockIdx.x * 256 + tid] = s.x + s.y + s.z + s.w;
+}
+
+template <int MODE>
+void run(const char *name)
+{
+    float *out;
+    hipMalloc(&out, 512 * 256 * 4 * 8);
+    const int nchunk = 4096, blocks = 512;                 // 2 workgroups per CU, one round
+    const size_t lds = 70 * 1024;                          // forces at most 2 workgroups per CU
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    k<MODE><<<blocks, 256, lds>>>(out, 64);
+    hipEventRecord(e0);
+    k<MODE><<<blocks, 256, lds>>>(out, nchunk);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double flops = (double)blocks * 4 * nchunk * 64 * 2048.0;
+    printf("%-58s %.3f ms  %.1f TFLOP/s  (%.1f %% of 157.3)\n", name, ms, flops / ms / 1e9, flops / ms / 1e9 / 157.3 * 100);
+    hipFree(out);
+}
+
+int main()
+{
+    run<0>("MFMA only");
+    run<4>("MFMA + barrier");
+    run<1>("MFMA + 32 v_pk_add_f32 up front");
+    run<2>("MFMA + 64 v_add_f32 up front");
+    run<17>("MFMA + 32 v_pk_add_f32 interleaved");
+    run<18>("MFMA + 64 v_add_f32 interleaved");
+    run<8>("MFMA + 32 ds_read_b64");
+    run<12>("MFMA + 32 ds_read_b64 + barrier");
+    run<13>("MFMA + pk adds + ds_read_b64 + barrier");
+    run<14>("MFMA + scalar adds + ds_read_b64 + barrier");
+    run<30>("MFMA + scalar adds interleaved + ds_read_b64 + barrier");
+    return 0;
+}
