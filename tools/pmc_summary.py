@@ -25,7 +25,7 @@ def short(name: str) -> str:
 
 
 def ours(n: str) -> bool:
-    return n.startswith(("conv_", "stft", "per_clip", "nhwc", "quantize", "wino"))
+    return n.startswith(("conv_", "stft", "per_clip", "nhwc", "quantize", "wino", "loss_", "gl_", "istft"))
 
 
 def read_counter(d, counter):
