@@ -200,15 +200,15 @@ __device__ __forceinline__ void vdft<8>(v2f *v)
 // four groups of 16 lanes over 32 banks (MI355X_MICROARCH.md, LDS).  Every read here is "32 lanes, 32 consecutive
 // elements", so ANY permutation inside aligned 32-element blocks keeps the reads conflict-free, and the permutation
 // is chosen per exchange so that the 16 lanes of a write group hit 16 distinct element residues mod 16:
-//   M = 512 (BASELINE's n_fft 1024; one frame per wave):
+//   M >= 128 (n_fft 256, 512 [the reference's], 1024 [BASELINE's]; 32 or 64 lanes per frame):
 //     X = 1: writes 8t+q          -> e'[1:0] = e[4:3], e'[3:2] = e[1:0] ^ e[6:5], e'[4] = e[2]
 //     X = 2: writes 64(t>>3)+(t&7)+8q -> e' = e ^ (e[6] << 3)
 //     X = 3: writes t+64q, reads k and M-k -> identity
-//   other sizes: one pad element per 8 (reads of the later passes are then 2-way conflicted; not the headline size).
+//   smaller sizes: one pad element per 8 (reads of the later passes are then 2-way conflicted).
 template <int M, int X>
 __device__ __forceinline__ int xidx(int e)
 {
-    if constexpr (M == 512) {
+    if constexpr (M >= 128) {
         if constexpr (X == 1) return (e & ~31) | ((e & 4) << 2) | ((((e & 3) ^ ((e >> 5) & 3))) << 2) | ((e >> 3) & 3);
         else if constexpr (X == 2) return e ^ ((e >> 3) & 8);
         else return e;
@@ -216,7 +216,7 @@ __device__ __forceinline__ int xidx(int e)
         return e + (e >> 3);
     }
 }
-template <int M> constexpr int exch_size() { return M == 512 ? M : M + M / 8; }
+template <int M> constexpr int exch_size() { return M >= 128 ? M : M + M / 8; }
 
 __device__ __forceinline__ void wave_lds_fence()
 {
@@ -578,7 +578,13 @@ hipError_t launch_stft_mag(const float *audio, int n_clips, long L, int n_fft, i
             case 64: return launch_wave<32, 1, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
             case 128: return launch_wave<64, 2, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
             case 256: return launch_wave<128, 4, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
-            case 512: return launch_wave<256, 8, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
+            case 512:
+                if (variant == 1) return launch_wave<256, 8, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
+                if (variant == 2) return launch_wave<256, 4, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
+                if (variant == 3) return launch_wave<256, 2, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
+                if (variant == 4) return launch_wave<256, 2, 32>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
+                // measured on 10 k x 3 s clips (ms): <8,16> 9.31, <4,16> 5.42, <2,32> 6.08, <2,16> 4.78, <4,32> 4.71
+                return launch_wave<256, 4, 32>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
             case 1024:
                 if (variant == 1) return launch_wave<512, 8, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
                 if (variant == 3) return launch_wave<512, 8, 32>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);

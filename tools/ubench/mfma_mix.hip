@@ -26,6 +26,12 @@ __global__ __launch_bounds__(256, 2) void k(float *out, int nchunk)
 #pragma unroll
     for (int i = 0; i < 32; ++i) B[i] = f32x2{0.5f, 0.25f * i};
     const f32x2 inc = {0.001f, 0.002f};
+    if constexpr (MODE & 32) {
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        if ((hwid >> 16) & 1) asm volatile("s_setprio 3"); else asm volatile("s_setprio 0");
+        if (blockIdx.x < 2 && tid == 0) out[1000000 + blockIdx.x] = (float)((hwid >> 16) & 15);
+    }
     for (int c = 0; c < nchunk; ++c) {
         if constexpr ((MODE & 1) && !(MODE & 16)) {
 #pragma unroll
@@ -47,6 +53,7 @@ __global__ __launch_bounds__(256, 2) void k(float *out, int nchunk)
             for (int i = 0; i < 32; ++i)
                 B[i] = *(const volatile f32x2 __attribute__((address_space(3))) *)(smem + ((tid & 63) * 2 + i * 128) % 4096);
         }
+        if constexpr (MODE & 64) asm volatile("s_setprio 3");
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             if constexpr (MODE & 16) {       // the chunk's VALU work spread over the four MFMA groups
@@ -73,6 +80,7 @@ __global__ __launch_bounds__(256, 2) void k(float *out, int nchunk)
                 for (int s = 0; s < 4; ++s)
                     acc[16 * j + 4 * g + s] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[4 * g + s].y, B[16 * j + 4 * g + s].y, acc[16 * j + 4 * g + s], 0, 0, 0);
         }
+        if constexpr (MODE & 64) asm volatile("s_setprio 0");
         if constexpr (MODE & 4) __syncthreads();
     }
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
@@ -85,7 +93,7 @@ template <int MODE>
 void run(const char *name)
 {
     float *out;
-    hipMalloc(&out, 512 * 256 * 4 * 8);
+    hipMalloc(&out, 8 << 20);
     const int nchunk = 4096, blocks = 512;                 // 2 workgroups per CU, one round
     const size_t lds = 70 * 1024;                          // forces at most 2 workgroups per CU
     hipFuncSetAttribute(reinterpret_cast<const void *>(k<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -113,5 +121,8 @@ int main()
     run<13>("MFMA + pk adds + ds_read_b64 + barrier");
     run<14>("MFMA + scalar adds + ds_read_b64 + barrier");
     run<30>("MFMA + scalar adds interleaved + ds_read_b64 + barrier");
+    run<13 + 32>("pk adds + ds_read_b64 + barrier, static prio by tg_id");
+    run<13 + 64>("pk adds + ds_read_b64 + barrier, prio 3 in MFMA phase");
+    run<13 + 96>("pk adds + ds_read_b64 + barrier, both");
     return 0;
 }
