@@ -11,7 +11,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // MODE bits: 1 = 32 v_pk_add_f32 per chunk, 2 = 64 v_add_f32 per chunk, 4 = s_barrier per chunk,
 //            8 = 32 ds_read_b64 per chunk feeding the B operands, 16 = VALU interleaved between MFMA groups
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void k(float *out, int nchunk)
+__global__ __launch_bounds__(256, MODE & 256 ? 3 : 2) void k(float *out, int nchunk)
 {
     extern __shared__ float smem[];
     const int tid = threadIdx.x;
@@ -33,6 +33,11 @@ __global__ __launch_bounds__(256, 2) void k(float *out, int nchunk)
         if (blockIdx.x < 2 && tid == 0) out[1000000 + blockIdx.x] = (float)((hwid >> 16) & 15);
     }
     for (int c = 0; c < nchunk; ++c) {
+        if constexpr ((MODE & 8) && (MODE & 128)) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i)
+                B[i] = *(const volatile f32x2 __attribute__((address_space(3))) *)(smem + ((tid & 63) * 2 + i * 128) % 4096);
+        }
         if constexpr ((MODE & 1) && !(MODE & 16)) {
 #pragma unroll
             for (int r = 0; r < 2; ++r)
@@ -48,7 +53,7 @@ __global__ __launch_bounds__(256, 2) void k(float *out, int nchunk)
                     asm volatile("v_add_f32 %0, %0, %1" : "+v"(V[i].y) : "v"(inc.y));
                 }
         }
-        if constexpr (MODE & 8) {
+        if constexpr ((MODE & 8) && !(MODE & 128)) {
 #pragma unroll
             for (int i = 0; i < 32; ++i)
                 B[i] = *(const volatile f32x2 __attribute__((address_space(3))) *)(smem + ((tid & 63) * 2 + i * 128) % 4096);
@@ -90,12 +95,12 @@ __global__ __launch_bounds__(256, 2) void k(float *out, int nchunk)
 }
 
 template <int MODE>
-void run(const char *name)
+void run(const char *name, int wg_per_cu = 2)
 {
     float *out;
     hipMalloc(&out, 8 << 20);
-    const int nchunk = 4096, blocks = 512;                 // 2 workgroups per CU, one round
-    const size_t lds = 70 * 1024;                          // forces at most 2 workgroups per CU
+    const int nchunk = 4096, blocks = 256 * wg_per_cu;     // one round of resident workgroups
+    const size_t lds = (wg_per_cu == 1 ? 100 : wg_per_cu == 2 ? 70 : 50) * 1024;   // caps the workgroups per CU
     hipFuncSetAttribute(reinterpret_cast<const void *>(k<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     k<MODE><<<blocks, 256, lds>>>(out, 64);
@@ -121,6 +126,11 @@ int main()
     run<13>("MFMA + pk adds + ds_read_b64 + barrier");
     run<14>("MFMA + scalar adds + ds_read_b64 + barrier");
     run<30>("MFMA + scalar adds interleaved + ds_read_b64 + barrier");
+    run<13>("pk adds + ds_read + barrier, ONE workgroup per CU", 1);
+    run<9>("pk adds + ds_read, no barrier, 2 per CU");
+    run<13 + 128>("ds_read issued before the pk adds + barrier");
+    run<13 + 256>("pk adds + ds_read + barrier, THREE workgroups per CU", 3);
+    run<0 + 256>("MFMA only, three per CU", 3);
     run<13 + 32>("pk adds + ds_read_b64 + barrier, static prio by tg_id");
     run<13 + 64>("pk adds + ds_read_b64 + barrier, prio 3 in MFMA phase");
     run<13 + 96>("pk adds + ds_read_b64 + barrier, both");
