@@ -11,11 +11,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // MODE bits: 1 = 32 v_pk_add_f32 per chunk, 2 = 64 v_add_f32 per chunk, 4 = s_barrier per chunk,
 //            8 = 32 ds_read_b64 per chunk feeding the B operands, 16 = VALU interleaved between MFMA groups
 template <int MODE>
-__global__ __launch_bounds__(256, MODE & 256 ? 3 : 2) void k(float *out, int nchunk)
+__global__ __launch_bounds__(256, MODE & 256 ? 3 : 2) void k(float *out, int nchunk, int noisy, unsigned long long *clk)
 {
     extern __shared__ float smem[];
     const int tid = threadIdx.x;
     for (int i = tid; i < 4096; i += 256) smem[i] = (float)(i & 7) * 0.125f;
+    if (tid == 0) smem[4096] = 0.f;
     __syncthreads();
     f32x4 acc[32];
 #pragma unroll
@@ -23,9 +24,20 @@ __global__ __launch_bounds__(256, MODE & 256 ? 3 : 2) void k(float *out, int nch
     f32x2 V[16], B[32];
 #pragma unroll
     for (int i = 0; i < 16; ++i) V[i] = f32x2{(float)(tid & 3) + i, 1.f};
+    if (noisy) {                                   // operands with busy mantissas: realistic switching activity
+        unsigned h = tid * 2654435761u + blockIdx.x * 40503u;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { h = h * 1664525u + 1013904223u; V[i].x = (float)(h >> 8) * (1.0f / 16777216.0f) - 0.5f; h = h * 1664525u + 1013904223u; V[i].y = (float)(h >> 8) * (1.0f / 16777216.0f) - 0.5f; }
+    }
 #pragma unroll
     for (int i = 0; i < 32; ++i) B[i] = f32x2{0.5f, 0.25f * i};
     const f32x2 inc = {0.001f, 0.002f};
+    if (noisy) {
+        unsigned h = tid * 97u + 12345u;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) { h = h * 1664525u + 1013904223u; B[i].x = (float)(h >> 8) * (1.0f / 16777216.0f) - 0.5f; h = h * 1664525u + 1013904223u; B[i].y = (float)(h >> 8) * (1.0f / 16777216.0f) - 0.5f; }
+    }
+    const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
     if constexpr (MODE & 32) {
         unsigned hwid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
@@ -61,6 +73,12 @@ __global__ __launch_bounds__(256, MODE & 256 ? 3 : 2) void k(float *out, int nch
         if constexpr (MODE & 64) asm volatile("s_setprio 3");
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
+            if constexpr (MODE & 512) {
+                if (g == 3) {
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    if ((tid & 63) == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(16384u), "v"(1u) : "memory");
+                }
+            }
             if constexpr (MODE & 16) {       // the chunk's VALU work spread over the four MFMA groups
                 if constexpr (MODE & 1) {
 #pragma unroll
@@ -87,7 +105,16 @@ __global__ __launch_bounds__(256, MODE & 256 ? 3 : 2) void k(float *out, int nch
         }
         if constexpr (MODE & 64) asm volatile("s_setprio 0");
         if constexpr (MODE & 4) __syncthreads();
+        if constexpr (MODE & 512) {
+            const unsigned target = 4u * (unsigned)(c + 1);
+            unsigned seen;
+            do {
+                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"(16384u) : "memory");
+                seen = __builtin_amdgcn_readfirstlane(seen);
+            } while (seen < target);
+        }
     }
+    if (blockIdx.x == 0 && tid == 0) { clk[0] = __builtin_readcyclecounter() - c0; clk[1] = __builtin_amdgcn_s_memrealtime() - r0; }
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 32; ++i) s += acc[i];
@@ -95,27 +122,35 @@ __global__ __launch_bounds__(256, MODE & 256 ? 3 : 2) void k(float *out, int nch
 }
 
 template <int MODE>
-void run(const char *name, int wg_per_cu = 2)
+void run(const char *name, int wg_per_cu = 2, int noisy = 0, int sustain = 0)
 {
-    float *out;
+    float *out; unsigned long long *clk; hipMalloc(&clk, 16);
     hipMalloc(&out, 8 << 20);
     const int nchunk = 4096, blocks = 256 * wg_per_cu;     // one round of resident workgroups
     const size_t lds = (wg_per_cu == 1 ? 100 : wg_per_cu == 2 ? 70 : 50) * 1024;   // caps the workgroups per CU
     hipFuncSetAttribute(reinterpret_cast<const void *>(k<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    k<MODE><<<blocks, 256, lds>>>(out, 64);
+    k<MODE><<<blocks, 256, lds>>>(out, 64, noisy, clk);
+    for (int rep = 0; rep < sustain; ++rep) k<MODE><<<blocks, 256, lds>>>(out, nchunk, noisy, clk);   // heat up
     hipEventRecord(e0);
-    k<MODE><<<blocks, 256, lds>>>(out, nchunk);
+    k<MODE><<<blocks, 256, lds>>>(out, nchunk, noisy, clk);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double flops = (double)blocks * 4 * nchunk * 64 * 2048.0;
-    printf("%-58s %.3f ms  %.1f TFLOP/s  (%.1f %% of 157.3)\n", name, ms, flops / ms / 1e9, flops / ms / 1e9 / 157.3 * 100);
+    unsigned long long hc[2]; hipMemcpy(hc, clk, 16, hipMemcpyDeviceToHost);
+    printf("%-58s %.3f ms  %.1f TFLOP/s  (%.1f %% of 157.3)  shader clock %.0f MHz\n", name, ms, flops / ms / 1e9, flops / ms / 1e9 / 157.3 * 100, (double)hc[0] / (double)hc[1] * 100.0);
     hipFree(out);
 }
 
 int main()
 {
     run<0>("MFMA only");
+    run<0>("MFMA only, random operands", 2, 1);
+    run<13>("pk adds + ds_read + barrier, random operands", 2, 1);
+    run<9 + 512>("pk adds + ds_read + SPLIT barrier (LDS counter)");
+    run<8 + 2 + 16 + 512>("scalar adds interleaved + ds_read + SPLIT barrier");
+    run<0>("MFMA only, random operands, after 3 s of the same", 2, 1, 400);
+    run<13>("pk adds + ds_read + barrier, random, after 4 s", 2, 1, 400);
     run<4>("MFMA + barrier");
     run<1>("MFMA + 32 v_pk_add_f32 up front");
     run<2>("MFMA + 64 v_add_f32 up front");
