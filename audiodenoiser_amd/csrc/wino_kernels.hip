@@ -174,7 +174,11 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
     const int b_lane = (q * WBN + ti) * 2;
 
     // diagnostic stamps (p.dbg != nullptr only; never in production): cycles per phase, summed over the chunks
+#ifdef ADN_WINO_STAMPS
     const bool stamp = p.dbg != nullptr;
+#else
+    constexpr bool stamp = false;                     // build with -DADN_WINO_STAMPS for the in-kernel phase stamps
+#endif
     unsigned long long tprev = 0, tsum[6] = {0, 0, 0, 0, 0, 0};
 #define ADN_STAMP(k)                                                                         \
     do {                                                                                     \
