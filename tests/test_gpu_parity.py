@@ -446,3 +446,23 @@ def test_griffin_lim_matches_oracle_and_reference_shapes(dev):
     from audiodenoiser_amd._lib import AdnError
     with pytest.raises(AdnError):
         griffin_lim_reconstruction(mag[:200], 512, 128)
+
+
+@pytest.mark.gpu
+def test_end_to_end_test_script_mirror(dev, tmp_path):
+    """tools/run_test_set.py = the reference's test.py flow (npy test set -> forward -> losses -> Griffin-Lim -> wav +
+    metrics files) on fabricated data; checks the artefacts test.py would leave behind."""
+    import subprocess
+    import sys
+    from audiodenoiser_amd.wav import read_wav
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    data, models, out = (str(tmp_path / d) for d in ("data", "models", "out"))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "run_test_set.py"), "--synthetic", "--data", data,
+                        "--models", models, "--out", out], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "processed noise types: ['white', 'urban']" in r.stdout
+    for nt in ("white", "urban"):
+        txt = open(os.path.join(out, f"{nt}_metrics.txt")).read()
+        assert txt.startswith(f"Perceptual metrics for noise type '{nt}':") and "Total Loss:" in txt and "L1 Loss:" in txt
+        audio, rate = read_wav(os.path.join(out, f"{nt}_denoised_0.wav"))
+        assert rate == 8000 and audio.shape == (128 * 187,) and np.isfinite(audio).all()
