@@ -258,3 +258,28 @@ def test_compat_modules_resolve_reference_import_names():
         spec.loader.exec_module(m)
         for n in names:
             assert getattr(m, n).__module__.startswith("audiodenoiser_amd.")
+
+
+def test_griffin_lim_entry_points_validate_arguments_without_a_device():
+    """Argument checks of the inverse-STFT / Griffin-Lim C ABI run before any HIP call (status 1 = ADN_ERR_INVALID,
+    3 = ADN_ERR_WORKSPACE), so they are testable on the CPU-only box."""
+    from audiodenoiser_amd import _lib
+    L = _lib.load()
+    n = ctypes.c_long()
+    assert L.adn_istft_length(188, 128, ctypes.byref(n)) == 0 and n.value == 128 * 187
+    assert L.adn_istft_length(0, 128, ctypes.byref(n)) == 1
+    need = ctypes.c_size_t()
+    assert L.adn_griffin_lim_workspace_bytes(2, 257, 188, ctypes.byref(need)) == 0
+    assert need.value == 2 * 188 * (257 * 2 + 512) * 4
+    assert L.adn_griffin_lim_workspace_bytes(0, 257, 188, ctypes.byref(need)) == 1
+    assert L.adn_istft_workspace_bytes(2, 188, 512, ctypes.byref(need)) == 0 and need.value == 2 * 188 * 512 * 4
+    assert L.adn_istft_workspace_bytes(2, 188, 500, ctypes.byref(need)) == 1
+    buf = (ctypes.c_float * 16)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert L.adn_griffin_lim(None, None, 1, 257, 188, 512, 128, 50, None, 0, None, None) == 1
+    assert L.adn_griffin_lim(p, p, 1, 257, 188, 500, 128, 50, p, 64, p, None) == 1            # n_fft not a power of two
+    assert L.adn_griffin_lim(p, p, 1, 200, 188, 512, 128, 50, p, 64, p, None) == 1            # n_bins != n_fft/2+1
+    assert b"n_bins" in L.adn_last_error()
+    assert L.adn_griffin_lim(p, p, 1, 257, 188, 512, 128, 50, p, 64, p, None) == 3            # workspace too small
+    assert L.adn_istft(p, 1, 188, 512, 1024, p, 1 << 30, p, None) == 1                         # hop > n_fft
+    assert L.adn_stft_complex(None, 1, 1000, 512, 128, None, None) == 1
