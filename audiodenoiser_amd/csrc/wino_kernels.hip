@@ -21,6 +21,8 @@
 //   have to agree).
 #include "adn_internal.h"
 
+#include <atomic>
+
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -363,15 +365,20 @@ hipError_t launch_wino_dma_n(ConvKind kind, const ConvArgs &a, hipStream_t st)
     if (nwg <= 0 || nwg > 0x7fffffffL) return hipErrorInvalidValue;
     if (!a2.zeros) return hipErrorInvalidValue;
     { const char *ab = std::getenv("ADN_WINO_ABLATE"); a2.ablate = ab ? std::atoi(ab) : 0; }   // timing experiments only
-    static bool attr_done = false;
-    if (!attr_done) {
+    // the attribute is per device: remember which devices of this process have it (one process per GPU is the
+    // deployment model, but a handle may be created on any device)
+    static std::atomic<unsigned long long> attr_mask{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(attr_mask.load(std::memory_order_acquire) & bit)) {
         hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_conv_dma_f32<CONV3X3_RELU_POOL, NW>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_conv_dma_f32<CONV3X3_RELU, NW>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e1 != hipSuccess) return e1;
         if (e2 != hipSuccess) return e2;
-        attr_done = true;
+        attr_mask.fetch_or(bit, std::memory_order_release);
     }
     a2.dbg = nullptr;
     const bool stamp = std::getenv("ADN_WINO_STAMP") != nullptr;      // diagnostic path only
