@@ -157,7 +157,8 @@ struct Plan {
 
 bool make_plan(int N, int F, int T, bool f16, Plan &p)
 {
-    if (N < 1 || F < 16 || T < 16) return false;
+    // T <= 4094: the first layer stages 10 rows x (T+2) floats in LDS; F*T*64 elements per image must index in int32
+    if (N < 1 || F < 16 || T < 16 || T > 4094 || (long)F * T > (1L << 24)) return false;
     p.N = N;
     p.H[0] = F;
     p.W[0] = T;
@@ -225,7 +226,7 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
 {
     if (!h || !x || !y) return fail(ADN_ERR_INVALID, "adn_unet_forward: null handle/x/y");
     Plan p;
-    if (!make_plan(N, F, T, h->f16, p)) return fail(ADN_ERR_INVALID, "adn_unet_forward: need N>=1 and F,T>=16");
+    if (!make_plan(N, F, T, h->f16, p)) return fail(ADN_ERR_INVALID, "adn_unet_forward: need N>=1, F,T>=16, T<=4094 and F*T<=2^24");
     if (!workspace || ws_bytes < p.total)
         return fail(ADN_ERR_WORKSPACE, "adn_unet_forward: workspace too small (see adn_unet_workspace_bytes)");
     int cur_dev = -1;
@@ -522,7 +523,7 @@ int adn_unet_workspace_bytes(const adn_unet *h, int N, int F, int T, size_t *byt
 {
     if (!bytes) return fail(ADN_ERR_INVALID, "adn_unet_workspace_bytes: null");
     Plan p;
-    if (!make_plan(N, F, T, h ? h->f16 : false, p)) return fail(ADN_ERR_INVALID, "adn_unet_workspace_bytes: need N>=1 and F,T>=16");
+    if (!make_plan(N, F, T, h ? h->f16 : false, p)) return fail(ADN_ERR_INVALID, "adn_unet_workspace_bytes: need N>=1, F,T>=16, T<=4094 and F*T<=2^24");
     *bytes = p.total;
     return ADN_OK;
 }

@@ -283,3 +283,13 @@ def test_griffin_lim_entry_points_validate_arguments_without_a_device():
     assert L.adn_griffin_lim(p, p, 1, 257, 188, 512, 128, 50, p, 64, p, None) == 3            # workspace too small
     assert L.adn_istft(p, 1, 188, 512, 1024, p, 1 << 30, p, None) == 1                         # hop > n_fft
     assert L.adn_stft_complex(None, 1, 1000, 512, 128, None, None) == 1
+
+
+def test_forward_shape_limits_are_reported():
+    from audiodenoiser_amd import _lib
+    L = _lib.load()
+    need = ctypes.c_size_t()
+    assert L.adn_unet_workspace_bytes(None, 1, 64, 4094, ctypes.byref(need)) == 0
+    assert L.adn_unet_workspace_bytes(None, 1, 64, 4096, ctypes.byref(need)) == 1
+    assert b"T<=4094" in L.adn_last_error()
+    assert L.adn_unet_workspace_bytes(None, 1, 8192, 4000, ctypes.byref(need)) == 1
