@@ -122,7 +122,10 @@ void pack_wino3x3(const float *w /*(Cout,Cin,3,3)*/, const std::vector<float> &s
                     U[x][v] = (tmp[x][0] * G[v][0] + tmp[x][1] * G[v][1] + tmp[x][2] * G[v][2]) * (double)scale[co];
             const int ct = co / BN, n = co % BN, ch = ci / 8, q = (ci % 8) / 2, e = ci & 1;
             float *blk = dst + ((size_t)ct * nchunk + ch) * (16 * 4 * BN * 2);
-            for (int pos = 0; pos < 16; ++pos) blk[((pos * 4 + q) * BN + n) * 2 + e] = (float)U[pos >> 2][pos & 3];
+            // slab layout [pos][j = n/16][q][n%16][e]: the 32 lanes (q, q+1) x 16 couts that one LDS read group serves
+            // are 64 consecutive dwords -> conflict-free ds_read_b64 (BN = 32)
+            for (int pos = 0; pos < 16; ++pos)
+                blk[((((pos * (BN / 16) + n / 16) * 4 + q) * 16) + (n % 16)) * 2 + e] = (float)U[pos >> 2][pos & 3];
         }
     (void)nct;
 }

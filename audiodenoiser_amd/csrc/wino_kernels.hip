@@ -51,7 +51,7 @@ __device__ __forceinline__ int wino_xcd_remap(int b, int nwg)
 // (1 KiB per wave instruction, no VGPR staging, no ds_write pass) into the image that is not being consumed; the
 // copy is issued in four slices between the MFMA groups of chunk c and lands under them; one barrier per chunk.
 //   LDS image (x2): halo rows of 37 sixteen-byte slots (18 pixels x 2 slots of 4 channels + 1 pad slot), 666 slots
-//   padded to 3 rounds of 256 lanes, then the U slab [pos][q][n][2] = 1024 slots = 4 rounds.
+//   padded to 3 rounds of 256 lanes, then the U slab [pos][j][q][n%16][2] = 1024 slots = 4 rounds.
 //   Lanes of pad / out-of-image slots read a 16-byte zero block (the convolution's zero padding comes for free).
 // Measured (in-kernel s_memtime stamps, profiles/): the kernel is bound by the CU's ingest path (~12 B/clk: 56 KB
 // per chunk per CU against 4096 MFMA cycles) and by the barrier-coupled patch/transform phases, not by the
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
 
     // patch reads (volatile: single ds_read_b64 each): at most 2-way bank conflicts with either halo layout
     const int a_lane = (2 * (2 * wr + (ti >> 3))) * DROW + 2 * (8 * wc + (ti & 7)) * PSTR + 2 * q;
-    const int b_lane = (q * WBN + ti) * 2;
+    const int b_lane = (q * 16 + ti) * 2;                    // U slab [pos][j][q][n%16][2]
 
     // diagnostic stamps (p.dbg != nullptr only; never in production): cycles per phase, summed over the chunks
 #ifdef ADN_WINO_STAMPS
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
 #define ADN_LOADU(dst, g)                                                                               \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                   \
         _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                   \
-            dst[j][s] = *reinterpret_cast<const f32x2 *>(sB + b_lane + 32 * j + (4 * (g) + s) * (4 * WBN * 2))
+            dst[j][s] = *(lds_cv_f32x2 *)(sB + b_lane + 128 * j + (4 * (g) + s) * (4 * WBN * 2))
 #define ADN_MFMAS(src, g)                                                                               \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                   \
         _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                   \
