@@ -122,8 +122,11 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
     for (int r = 0; r < HR; ++r) {
         const int s = r * NT + tid;
         const int row = s / G::RSLOTS, k = s - row * G::RSLOTS;
-        const int pix = k / G::SPP, part = k - pix * G::SPP;
-        const bool data = s < G::HUSED && part < 2 && pix < G::HW;
+        // NW == 4: the row's pad slot sits in the MIDDLE (physical slot 16), so pixels 8.. are shifted by 16 bytes and
+        // the 8 even pixels a patch read touches fall on 8 different bank quads (see a_lane below)
+        const int lk = (NW == 4) ? (k < 16 ? k : k - 1) : k;          // logical slot = pixel * 2 + part
+        const int pix = lk / G::SPP, part = lk - pix * G::SPP;
+        const bool data = s < G::HUSED && !(NW == 4 && k == 16) && pix < G::HW;
         const int gy = gy0 + row, gx = gx0 + pix;
         const int y0 = gy - p.s0.offY, x0 = gx - p.s0.offX;
         hcur[r] = (data && y0 >= 0 && y0 < p.s0.H && x0 >= 0 && x0 < p.s0.W) ? (y0 * p.s0.W + x0) * p.s0.C + part * 4 : -1;
@@ -171,8 +174,16 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
         for (int s = 0; s < 16; ++s) acc[j][s] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // patch reads (volatile: single ds_read_b64 each): at most 2-way bank conflicts with either halo layout
-    const int a_lane = (2 * (2 * wr + (ti >> 3))) * DROW + 2 * (8 * wc + (ti & 7)) * PSTR + 2 * q;
+    // patch reads: lane (q, ti) reads channels 2q, 2q+1 of pixel column 2*(tile column) + b.  In a 32-lane LDS read
+    // group the 8 tile columns are 16 dwords apart = only 4 distinct bank quads of 64; with the row's pad slot moved
+    // to the middle (NW == 4) columns 8.. are 4 dwords further and all 16 (2 rows x 8 columns) quads differ.
+    int a_lane[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int col = 2 * (8 * wc + (ti & 7)) + b;
+        const int shift = (NW == 4 && 2 * col + (q >> 1) >= 16) ? 4 : 0;
+        a_lane[b] = (2 * (2 * wr + (ti >> 3))) * DROW + col * PSTR + 2 * q + shift;
+    }
     const int b_lane = (q * 16 + ti) * 2;                    // U slab [pos][j][q][n%16][2]
 
     // diagnostic stamps (p.dbg != nullptr only; never in production): cycles per phase, summed over the chunks
@@ -213,7 +224,7 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) d[a][b] = *(lds_cv_f32x2 *)(sA + a_lane + a * DROW + b * PSTR);
+            for (int b = 0; b < 4; ++b) d[a][b] = *(lds_cv_f32x2 *)(sA + a_lane[b] + a * DROW);
         ADN_STAMP(1);                                     // patch reads landed
         f32x2 t[4][4];
 #pragma unroll
