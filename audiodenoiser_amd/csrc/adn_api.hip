@@ -122,10 +122,11 @@ void pack_wino3x3(const float *w /*(Cout,Cin,3,3)*/, const std::vector<float> &s
                     U[x][v] = (tmp[x][0] * G[v][0] + tmp[x][1] * G[v][1] + tmp[x][2] * G[v][2]) * (double)scale[co];
             const int ct = co / BN, n = co % BN, ch = ci / 8, q = (ci % 8) / 2, e = ci & 1;
             float *blk = dst + ((size_t)ct * nchunk + ch) * (16 * 4 * BN * 2);
-            // slab layout [pos][j = n/16][q][n%16][e]: the 32 lanes (q, q+1) x 16 couts that one LDS read group serves
-            // are 64 consecutive dwords -> conflict-free ds_read_b64 (BN = 32)
+            // slab layout [pos/2][j = n/16][q][n%16][pos%2][e]: a wave's B-fragment read of one (position pair, cout
+            // block) is 64 lanes x 16 bytes = 1 KB contiguous -> one conflict-free ds_read_b128 (BN = 32)
             for (int pos = 0; pos < 16; ++pos)
-                blk[((((pos * (BN / 16) + n / 16) * 4 + q) * 16) + (n % 16)) * 2 + e] = (float)U[pos >> 2][pos & 3];
+                blk[(((((pos >> 1) * (BN / 16) + n / 16) * 4 + q) * 16) + (n % 16)) * 4 + (pos & 1) * 2 + e] =
+                    (float)U[pos >> 2][pos & 3];
         }
     (void)nct;
 }

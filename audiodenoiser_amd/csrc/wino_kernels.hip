@@ -33,6 +33,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // volatile LDS view: keeps each patch read a single ds_read_b64 (see the bank note in the kernel)
 typedef const volatile f32x2 __attribute__((address_space(3))) lds_cv_f32x2;
+typedef const volatile f32x4 __attribute__((address_space(3))) lds_cv_f32x4;
 
 namespace {
 
@@ -51,7 +52,7 @@ __device__ __forceinline__ int wino_xcd_remap(int b, int nwg)
 // (1 KiB per wave instruction, no VGPR staging, no ds_write pass) into the image that is not being consumed; the
 // copy is issued in four slices between the MFMA groups of chunk c and lands under them; one barrier per chunk.
 //   LDS image (x2): halo rows of 37 sixteen-byte slots (18 pixels x 2 slots of 4 channels + 1 pad slot), 666 slots
-//   padded to 3 rounds of 256 lanes, then the U slab [pos][j][q][n%16][2] = 1024 slots = 4 rounds.
+//   padded to 3 rounds of 256 lanes, then the U slab [pos/2][j][q][n%16][pos%2][2] = 1024 slots = 4 rounds.
 //   Lanes of pad / out-of-image slots read a 16-byte zero block (the convolution's zero padding comes for free).
 // Measured (in-kernel s_memtime stamps, profiles/): the kernel is bound by the CU's ingest path (~12 B/clk: 56 KB
 // per chunk per CU against 4096 MFMA cycles) and by the barrier-coupled patch/transform phases, not by the
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
         const int shift = (NW == 4 && 2 * col + (q >> 1) >= 16) ? 4 : 0;
         a_lane[b] = (2 * (2 * wr + (ti >> 3))) * DROW + col * PSTR + 2 * q + shift;
     }
-    const int b_lane = (q * 16 + ti) * 2;                    // U slab [pos][j][q][n%16][2]
+    const int b_lane = (q * 16 + ti) * 4;                    // U slab [pos/2][j][q][n%16][pos%2][2]
 
     // diagnostic stamps (p.dbg != nullptr only; never in production): cycles per phase, summed over the chunks
 #ifdef ADN_WINO_STAMPS
@@ -246,10 +247,13 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
         // read(g+1) is issued right after the wait for g (forced by an empty asm that consumes the last register of
         // group g) and flies under group g's 16 MFMAs.  sched_barrier(0) pins the order.
         f32x2 ua[2][4], ub[2][4];
-#define ADN_LOADU(dst, g)                                                                               \
+#define ADN_LOADU(dst, g)                                   /* 4 x ds_read_b128: two positions per read */ \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                   \
-        _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                   \
-            dst[j][s] = *(lds_cv_f32x2 *)(sB + b_lane + 128 * j + (4 * (g) + s) * (4 * WBN * 2))
+        _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                 \
+            const f32x4 v_ = *(lds_cv_f32x4 *)(sB + b_lane + ((2 * (g) + h) * 2 + j) * 256);            \
+            dst[j][2 * h] = f32x2{v_.x, v_.y};                                                          \
+            dst[j][2 * h + 1] = f32x2{v_.z, v_.w};                                                      \
+        }
 #define ADN_MFMAS(src, g)                                                                               \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                   \
         _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                   \
