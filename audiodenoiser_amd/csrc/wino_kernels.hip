@@ -54,9 +54,12 @@ __device__ __forceinline__ int wino_xcd_remap(int b, int nwg)
 //   LDS image (x2): halo rows of 37 sixteen-byte slots (18 pixels x 2 slots of 4 channels + 1 pad slot), 666 slots
 //   padded to 3 rounds of 256 lanes, then the U slab [pos/2][j][q][n%16][pos%2][2] = 1024 slots = 4 rounds.
 //   Lanes of pad / out-of-image slots read a 16-byte zero block (the convolution's zero padding comes for free).
-// Measured (in-kernel s_memtime stamps, profiles/): the kernel is bound by the CU's ingest path (~12 B/clk: 56 KB
-// per chunk per CU against 4096 MFMA cycles) and by the barrier-coupled patch/transform phases, not by the
-// matrix cores (65 % busy).
+//   The halo row's pad slot sits in the middle (physical slot 16) and the U slab is pair-interleaved so that both
+//   read patterns are bank-conflict free at full LDS rate.
+// Measured (ablations and tools/ubench/mfma_mix.hip, profiles/): 68 % MFMA busy; what it is sensitive to is the data
+// movement per chunk -- copied bytes (+13 % cost 8 %), the length of the LDS read burst behind the barrier (fixing
+// two read layouts gained 3.5 % at 15 % LDS load) -- not the synchronisation form (split barrier, woven transform,
+// wave priorities and start stagger all measured within +-1 %).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void dma16(const float *g, float *lds_wave_base)
 {
