@@ -466,3 +466,25 @@ def test_end_to_end_test_script_mirror(dev, tmp_path):
         assert txt.startswith(f"Perceptual metrics for noise type '{nt}':") and "Total Loss:" in txt and "L1 Loss:" in txt
         audio, rate = read_wav(os.path.join(out, f"{nt}_denoised_0.wav"))
         assert rate == 8000 and audio.shape == (128 * 187,) and np.isfinite(audio).all()
+
+
+@pytest.mark.gpu
+def test_forward_is_stream_capturable(net, dev):
+    """The launch sequence only enqueues on the caller's stream (no allocation, no synchronisation), so it can be
+    captured into a HIP graph and replayed — what a serving loop does to drop the 23 launch overheads at batch 1."""
+    x = torch.rand((1, 1, 64, 48), device=dev) * 3
+    with torch.no_grad():
+        ref = net(x).clone()                       # warm-up: packs weights, sizes the workspace
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            net(x)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            y = net(x)
+        x.copy_(torch.rand((1, 1, 64, 48), device=dev) * 3)
+        graph.replay()
+        torch.cuda.synchronize()
+        again = net(x)
+    assert torch.equal(y, again) and not torch.equal(y, ref)
