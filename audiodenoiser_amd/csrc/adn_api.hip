@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -59,6 +60,10 @@ struct adn_unet {
     bool f16 = false;              // fp16 storage + fp16 MFMA (fp32 accumulate); x and y stay fp32 at the ABI
     bool use_wino = true;          // fp32 3x3 layers: Winograd F(2x2,3x3) kernel (false: direct implicit GEMM)
     int wino_bn = 32;              // couts per Winograd workgroup
+    // split-K for layers that cannot fill the chip at small batch (ADN_WINO_SPLITK=1 when the handle is created).
+    // Off by default: it changes the summation order, and the default path keeps a clip's result bit-identical
+    // whatever batch it is computed in.
+    bool allow_split = false;
     size_t zeros_off = 0;          // 64 zero floats inside the packed buffer
 };
 
@@ -156,7 +161,7 @@ void pack_convt(const float *w /*(Cin,Cout,2,2)*/, int Cin, int Cout, T *dst)
 
 struct Plan {
     int N, H[5], W[5];
-    size_t tA, tB, skip[4], pool[4], total;   // BYTE offsets into the workspace
+    size_t tA, tB, skip[4], pool[4], part, total;   // BYTE offsets into the workspace (part: split-K partial sums)
 };
 
 bool make_plan(int N, int F, int T, bool f16, Plan &p)
@@ -183,6 +188,24 @@ bool make_plan(int N, int F, int T, bool f16, Plan &p)
     for (int l = 0; l < 4; ++l) {
         p.skip[l] = take((size_t)N * p.H[l] * p.W[l] * CH[l]);
         p.pool[l] = take((size_t)N * p.H[l + 1] * p.W[l + 1] * CH[l]);
+    }
+    // split-K partial sums (fp32 Winograd path, small batches only): the largest ksplit * N*H*W*Cout over the 3x3 layers
+    p.part = o;
+    if (!f16) {
+        size_t need = 0;
+        auto layer = [&](int l, int cin, int cout) {
+            adn::ConvArgs a{};
+            a.N = N; a.H = p.H[l]; a.W = p.W[l];
+            a.tilesY = (p.H[l] + 15) / 16;
+            a.nct = cout / 32;
+            const int ks = adn::wino_ksplit(adn::wino_workgroups(a), cin / 8);
+            if (ks > 1) need = std::max(need, (size_t)ks * N * p.H[l] * p.W[l] * cout);
+        };
+        for (int l = 1; l < 4; ++l) { layer(l, CH[l - 1], CH[l]); layer(l, CH[l], CH[l]); }
+        layer(0, 64, 64);
+        layer(4, 512, 1024); layer(4, 1024, 1024);
+        for (int l = 3; l >= 0; --l) { layer(l, 2 * CH[l], CH[l]); layer(l, CH[l], CH[l]); }
+        o += (need * 4 + 255) & ~size_t(255);
     }
     p.total = o;
     return true;
@@ -217,12 +240,19 @@ adn::ConvArgs conv_args(const adn_unet *h, const Conv3x3Layer &L, adn::ConvKind 
     a.ablate = 0;
     a.zeros = h->dev + h->zeros_off;
     a.dbg = nullptr;
+    a.ksplit = 1;
+    a.nwg_base = 0;
+    a.partial = nullptr;
     return a;
 }
 
-hipError_t launch_conv3(const adn_unet *h, adn::ConvKind kind, const adn::ConvArgs &a, hipStream_t st)
+hipError_t launch_conv3(const adn_unet *h, adn::ConvKind kind, const adn::ConvArgs &a, float *partial, hipStream_t st)
 {
-    return h->use_wino ? adn::launch_wino_conv(kind, a, st) : adn::launch_conv_mfma(kind, a, h->f16, st);
+    if (!h->use_wino) return adn::launch_conv_mfma(kind, a, h->f16, st);
+    adn::ConvArgs a2 = a;
+    a2.ksplit = h->allow_split ? adn::wino_ksplit(adn::wino_workgroups(a), a.nchunk) : 1;
+    a2.partial = partial;
+    return adn::launch_wino_conv(kind, a2, st);
 }
 
 int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, void *workspace, size_t ws_bytes,
@@ -239,6 +269,7 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
 
     char *ws = static_cast<char *>(workspace);      // activations are fp32 or fp16 (h->f16); offsets are bytes
     void *tA = ws + p.tA, *tB = ws + p.tB;
+    float *part = reinterpret_cast<float *>(ws + p.part);      // split-K partial sums (small batches)
     const bool f16 = h->f16;
     // timing hook: events[slot*(L+1) + k] is recorded before launch k (k = L: after the last one)
     const bool timed = h->timing_max > 0 && h->timing_count < h->timing_max && !taps;
@@ -265,14 +296,14 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
             adn::ConvArgs a = conv_args(h, h->c3[li], adn::CONV3X3_RELU, ws + p.pool[l - 1], CH[l - 1], nullptr, 0, 0, 0,
                                         tA, nullptr, N, p.H[l], p.W[l]);
             ADN_MARK();
-            ADN_HIP(launch_conv3(h, adn::CONV3X3_RELU, a, st));
+            ADN_HIP(launch_conv3(h, adn::CONV3X3_RELU, a, part, st));
             ++li;
             cur = tA;
         }
         adn::ConvArgs a = conv_args(h, h->c3[li], adn::CONV3X3_RELU_POOL, cur, CH[l], nullptr, 0, 0, 0, skip, pool, N,
                                     p.H[l], p.W[l]);
         ADN_MARK();
-        ADN_HIP(launch_conv3(h, adn::CONV3X3_RELU_POOL, a, st));
+        ADN_HIP(launch_conv3(h, adn::CONV3X3_RELU_POOL, a, part, st));
         ++li;
         ADN_HIP(export_tap(l, skip, CH[l], p.H[l], p.W[l]));
     }
@@ -281,12 +312,12 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
         adn::ConvArgs a = conv_args(h, h->c3[li], adn::CONV3X3_RELU, ws + p.pool[3], 512, nullptr, 0, 0, 0, tA, nullptr, N,
                                     p.H[4], p.W[4]);
         ADN_MARK();
-        ADN_HIP(launch_conv3(h, adn::CONV3X3_RELU, a, st));
+        ADN_HIP(launch_conv3(h, adn::CONV3X3_RELU, a, part, st));
         ++li;
         adn::ConvArgs b = conv_args(h, h->c3[li], adn::CONV3X3_RELU, tA, 1024, nullptr, 0, 0, 0, tB, nullptr, N, p.H[4],
                                     p.W[4]);
         ADN_MARK();
-        ADN_HIP(launch_conv3(h, adn::CONV3X3_RELU, b, st));
+        ADN_HIP(launch_conv3(h, adn::CONV3X3_RELU, b, part, st));
         ++li;
         ADN_HIP(export_tap(4, tB, 1024, p.H[4], p.W[4]));
     }
@@ -315,17 +346,20 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
         t.ablate = 0;
         t.zeros = h->dev + h->zeros_off;
         t.dbg = nullptr;
+        t.ksplit = 1;
+        t.nwg_base = 0;
+        t.partial = nullptr;
         ADN_MARK();
         ADN_HIP(adn::launch_conv_mfma(adn::CONVT2X2, t, f16, st));
         // first conv of the DoubleConv reads cat([skip, x1]) virtually
         adn::ConvArgs a = conv_args(h, h->c3[li], adn::CONV3X3_RELU, ws + p.skip[l], co, Y, co, 2 * uh, 2 * uw, X, nullptr,
                                     N, p.H[l], p.W[l]);
         ADN_MARK();
-        ADN_HIP(launch_conv3(h, adn::CONV3X3_RELU, a, st));
+        ADN_HIP(launch_conv3(h, adn::CONV3X3_RELU, a, part, st));
         ++li;
         adn::ConvArgs b = conv_args(h, h->c3[li], adn::CONV3X3_RELU, X, co, nullptr, 0, 0, 0, Y, nullptr, N, p.H[l], p.W[l]);
         ADN_MARK();
-        ADN_HIP(launch_conv3(h, adn::CONV3X3_RELU, b, st));
+        ADN_HIP(launch_conv3(h, adn::CONV3X3_RELU, b, part, st));
         ++li;
         ADN_HIP(export_tap(5 + (3 - l), Y, co, p.H[l], p.W[l]));
         void *tmp = X;
@@ -397,6 +431,7 @@ int adn_unet_create_ex(adn_unet **handle, int device, const float *const *t, int
     if (const char *algo = std::getenv("ADN_CONV_ALGO"))       // "direct": implicit-GEMM kernel instead of Winograd
         h->use_wino = std::strcmp(algo, "direct") != 0;
     if (h->f16) h->use_wino = false;                           // the fp16 path runs the direct fp16-MFMA kernels
+    if (const char *sk = std::getenv("ADN_WINO_SPLITK")) h->allow_split = std::atoi(sk) != 0;
     std::vector<float> host;
     auto reserve = [&](size_t n) {
         const size_t at = host.size();

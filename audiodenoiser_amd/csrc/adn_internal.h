@@ -29,7 +29,22 @@ struct ConvArgs {
     int ablate;            // timing experiments only (ADN_WINO_ABLATE); 0 in production
     const float *zeros;    // >= 16 bytes of zeros in device memory (source of padding lanes of the LDS-DMA copy)
     void *dbg;             // diagnostic stamp buffer (ADN_WINO_STAMP); nullptr in production
+    // split-K (small batches, Winograd kernel only): `ksplit` workgroups share one output tile, each sums a slice
+    // of nchunk/ksplit chunks and writes raw partial sums to `partial` [split][N][H][W][Cout]; a second launch adds
+    // them in a fixed order and applies bias / ReLU / pooling.  ksplit = 1: everything in one launch.
+    int ksplit;
+    int nwg_base;          // workgroups per split (grid = nwg_base * ksplit)
+    float *partial;
 };
+
+// Number of K splits for a 3x3 layer launched as `nwg` Winograd workgroups of `nchunk` chunks: only when the grid
+// cannot fill the 512 workgroup slots of the chip (2 per CU) and the K loop is long enough to be worth cutting.
+inline int wino_ksplit(long nwg, int nchunk)
+{
+    int ks = 1;
+    while (ks < 8 && nwg * ks * 2 <= 512 && nchunk % (ks * 2) == 0 && nchunk / (ks * 2) >= 4) ks *= 2;
+    return ks;
+}
 
 enum ConvKind { CONV3X3_RELU = 0, CONV3X3_RELU_POOL = 1, CONVT2X2 = 2 };
 
@@ -45,6 +60,8 @@ ConvGeom conv_geom(ConvKind kind, int Cout, bool f16);
 hipError_t launch_conv_mfma(ConvKind kind, const ConvArgs &a, bool f16, hipStream_t st);
 // Winograd F(2x2,3x3) variant of the 3x3 kinds, fp32 only (wino_kernels.hip): tile 16x16 px x 32 couts, 8-ch chunks.
 hipError_t launch_wino_conv(ConvKind kind, const ConvArgs &a, hipStream_t st);
+// workgroups of one K split of a Winograd launch (what wino_ksplit() is asked about)
+long wino_workgroups(const ConvArgs &a);
 
 // First layer: Conv2d(1 -> 64, 3x3, pad 1) + folded BN + ReLU, fp32 input, NHWC output.  w9x64: [tap][cout].
 hipError_t launch_conv_first(const float *x, const float *w9x64, const float *bias, void *out, bool f16,

@@ -87,7 +87,9 @@ struct DmaGeom {
     static constexpr int SUP = NW == 8 ? 32 : 64;          // workgroups resident on one XCD
 };
 
-template <int EPI, int NW>
+// SPLIT = 1: split-K launch for small batches (see ConvArgs::ksplit): the workgroup sums chunks [c0, c0 + nchunk/ksplit)
+// and stores raw partial sums; wino_reduce_kernel finishes the layer.
+template <int EPI, int NW, int SPLIT>
 __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_conv_dma_f32(const ConvArgs p)
 {
     using G = DmaGeom<NW>;
@@ -104,7 +106,10 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
     // Workgroup -> (pixel tile, cout tile).  After the XCD remap, SUP consecutive ids run together on one XCD;
     // they form a supertile of gc cout tiles x gp pixel tiles so that every U slab and every halo is fetched into
     // that XCD's L2 once and hit by the other workgroups of the supertile.
-    int lid = wino_xcd_remap(blockIdx.x, gridDim.x);
+    const int split = SPLIT ? (int)blockIdx.x / p.nwg_base : 0;
+    const int nloc = SPLIT ? p.nchunk / p.ksplit : p.nchunk;      // chunks this workgroup sums
+    const int c0 = split * nloc;                                   // first of them
+    int lid = SPLIT ? wino_xcd_remap((int)blockIdx.x - split * p.nwg_base, p.nwg_base) : wino_xcd_remap(blockIdx.x, gridDim.x);
     const int gc = p.nct < 8 ? p.nct : 8, gp = G::SUP / gc;
     const int ncg = p.nct / gc;
     const int sg = lid / G::SUP, wl = lid - sg * G::SUP;
@@ -139,7 +144,16 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
     }
     const float *srcp = static_cast<const float *>(p.s0.ptr) + (size_t)n * p.s0.H * p.s0.W * p.s0.C;   // next chunk's channels
     const float *base1 = static_cast<const float *>(p.s1.ptr) + (size_t)n * p.s1.H * p.s1.W * p.s1.C;
-    const float *wp = static_cast<const float *>(p.wpk) + (size_t)ct * p.nchunk * 4096 + tid * 4;
+    const float *wp = static_cast<const float *>(p.wpk) + ((size_t)ct * p.nchunk + c0) * 4096 + tid * 4;
+    if (SPLIT) {
+        if (c0 >= p.nchunk0) {                            // the slice starts inside the second source (virtual concat)
+            srcp = base1 + (size_t)(c0 - p.nchunk0) * WKC;
+#pragma unroll
+            for (int r = 0; r < HR; ++r) hcur[r] = hsec[r];
+        } else {
+            srcp += (size_t)c0 * WKC;
+        }
+    }
     const float *zsrc = p.zeros;
 
 #define ADN_DMA_BEGIN(c)                                                                       \
@@ -208,19 +222,19 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
             tprev = t_;                                                                      \
         }                                                                                    \
     } while (0)
-    ADN_DMA(0, 0);
+    ADN_DMA(c0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (stamp) {
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
     }
-    for (int c = 0; c < p.nchunk; ++c) {
+    for (int c = 0; c < nloc; ++c) {                  // c counts this workgroup's chunks; the layer's chunk is c0 + c
         // the copy of chunk c+1 is issued in four slices between the MFMA groups below: a wave stalled in VMEM issue
         // (back-pressure of the CU's ~12 B/clk ingest path) then overlaps its SIMD partner's MFMAs instead of
         // delaying its own
-        const bool more = c + 1 < p.nchunk && !((p.ablate & 1) && c >= 1);   // ablate&1: timing experiment, no copies
+        const bool more = c + 1 < nloc && !((p.ablate & 1) && c >= 1);   // ablate&1: timing experiment, no copies
         const int nb = (c + 1) & 1;
-        if (more) ADN_DMA_BEGIN(c + 1);
+        if (more) ADN_DMA_BEGIN(c0 + c + 1);
         ADN_STAMP(0);
         const float *sA = smem + (c & 1) * DBUF;
         const float *sB = sA + HR * NT * 4;
@@ -326,7 +340,7 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
         unsigned long long *o = reinterpret_cast<unsigned long long *>(p.dbg) + ((size_t)blockIdx.x * NW + wave) * 8;
 #pragma unroll
         for (int k = 0; k < 6; ++k) o[k] = tsum[k];
-        o[6] = (unsigned long long)p.nchunk;
+        o[6] = (unsigned long long)nloc;
     }
 
     const int Hp = p.H >> 1, Wp = p.W >> 1;
@@ -352,6 +366,15 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
             y[0][1] = s1[0] + s1[1] + s1[2];
             y[1][1] = s1[1] - s1[2] - s1[3];
             const int gy = ty * WT + 2 * tyw, gx = tx * G::TPW + 2 * txw;
+            if constexpr (SPLIT == 1) {
+                float *pp = p.partial + ((size_t)split * p.N + n) * p.H * p.W * p.Cout + col;
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        if (gy + a < p.H && gx + b < p.W) pp[((size_t)(gy + a) * p.W + gx + b) * p.Cout] = y[a][b];
+                continue;
+            }
             float mx = 0.f;
 #pragma unroll
             for (int a = 0; a < 2; ++a)
@@ -367,6 +390,43 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
             }
         }
     }
+}
+
+// Second launch of a split-K layer: out = ReLU(sum over splits (fixed order) + bias), plus the 2x2 max-pool.
+// One thread per (2x2 pixel block, 4 output channels).
+template <int EPI>
+__global__ __launch_bounds__(256) void wino_reduce_kernel(const float *__restrict__ partial, const float *__restrict__ bias,
+                                                          float *__restrict__ out, float *__restrict__ pool, int ksplit,
+                                                          int N, int H, int W, int Cout)
+{
+    const int cq = Cout / 4, bh = (H + 1) / 2, bw = (W + 1) / 2;
+    const long total = (long)N * bh * bw * cq;
+    const long id = (long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= total) return;
+    const int c4 = (int)(id % cq) * 4;
+    long r = id / cq;
+    const int bx = (int)(r % bw);
+    r /= bw;
+    const int by = (int)(r % bh), n = (int)(r / bh);
+    const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + c4);
+    const size_t img = (size_t)H * W * Cout, split_stride = (size_t)N * img;
+    f32x4 mx = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int gy = 2 * by + a, gx = 2 * bx + b;
+            if (gy >= H || gx >= W) continue;
+            const size_t o = (size_t)n * img + ((size_t)gy * W + gx) * Cout + c4;
+            f32x4 v = *reinterpret_cast<const f32x4 *>(partial + o);
+            for (int s = 1; s < ksplit; ++s) v += *reinterpret_cast<const f32x4 *>(partial + s * split_stride + o);
+            v += bv;
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            *reinterpret_cast<f32x4 *>(out + o) = v;
+            mx.x = fmaxf(mx.x, v.x); mx.y = fmaxf(mx.y, v.y); mx.z = fmaxf(mx.z, v.z); mx.w = fmaxf(mx.w, v.w);
+        }
+    if (EPI == CONV3X3_RELU_POOL && by < H / 2 && bx < W / 2)
+        *reinterpret_cast<f32x4 *>(pool + (((size_t)n * (H / 2) + by) * (W / 2) + bx) * Cout + c4) = mx;
 }
 
 template <int NW>
@@ -390,12 +450,15 @@ hipError_t launch_wino_dma_n(ConvKind kind, const ConvArgs &a, hipStream_t st)
     if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(attr_mask.load(std::memory_order_acquire) & bit)) {
-        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_conv_dma_f32<CONV3X3_RELU_POOL, NW>),
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_conv_dma_f32<CONV3X3_RELU_POOL, NW, 0>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_conv_dma_f32<CONV3X3_RELU, NW>),
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_conv_dma_f32<CONV3X3_RELU, NW, 0>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_conv_dma_f32<CONV3X3_RELU, NW, 1>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e1 != hipSuccess) return e1;
         if (e2 != hipSuccess) return e2;
+        if (e3 != hipSuccess) return e3;
         attr_mask.fetch_or(bit, std::memory_order_release);
     }
     a2.dbg = nullptr;
@@ -405,11 +468,32 @@ hipError_t launch_wino_dma_n(ConvKind kind, const ConvArgs &a, hipStream_t st)
         if (hipMalloc(&a2.dbg, dbg_bytes) != hipSuccess) return hipErrorOutOfMemory;
         (void)hipMemsetAsync(a2.dbg, 0, dbg_bytes, st);
     }
+    hipError_t le;
+    if (a2.ksplit > 1) {
+        // split-K: raw partial sums first (the epilogue variant does not matter), then sum + bias + ReLU (+ pool)
+        if (!a2.partial || a2.nchunk % a2.ksplit || (a2.Cout & 3)) return hipErrorInvalidValue;
+        a2.nwg_base = (int)nwg;
+        hipLaunchKernelGGL((wino_conv_dma_f32<CONV3X3_RELU, NW, 1>), dim3((unsigned)(nwg * a2.ksplit)), dim3(64 * NW), lds,
+                           st, a2);
+        le = hipGetLastError();
+        if (le != hipSuccess) return le;
+        const long items = (long)a2.N * ((a2.H + 1) / 2) * ((a2.W + 1) / 2) * (a2.Cout / 4);
+        const unsigned blocks = (unsigned)((items + 255) / 256);
+        if (kind == CONV3X3_RELU_POOL)
+            hipLaunchKernelGGL(wino_reduce_kernel<CONV3X3_RELU_POOL>, dim3(blocks), dim3(256), 0, st, a2.partial, a2.bias,
+                               static_cast<float *>(a2.out), static_cast<float *>(a2.pool), a2.ksplit, a2.N, a2.H, a2.W,
+                               a2.Cout);
+        else
+            hipLaunchKernelGGL(wino_reduce_kernel<CONV3X3_RELU>, dim3(blocks), dim3(256), 0, st, a2.partial, a2.bias,
+                               static_cast<float *>(a2.out), static_cast<float *>(nullptr), a2.ksplit, a2.N, a2.H, a2.W,
+                               a2.Cout);
+        return hipGetLastError();
+    }
     if (kind == CONV3X3_RELU_POOL)
-        hipLaunchKernelGGL((wino_conv_dma_f32<CONV3X3_RELU_POOL, NW>), dim3((unsigned)nwg), dim3(64 * NW), lds, st, a2);
+        hipLaunchKernelGGL((wino_conv_dma_f32<CONV3X3_RELU_POOL, NW, 0>), dim3((unsigned)nwg), dim3(64 * NW), lds, st, a2);
     else
-        hipLaunchKernelGGL((wino_conv_dma_f32<CONV3X3_RELU, NW>), dim3((unsigned)nwg), dim3(64 * NW), lds, st, a2);
-    hipError_t le = hipGetLastError();
+        hipLaunchKernelGGL((wino_conv_dma_f32<CONV3X3_RELU, NW, 0>), dim3((unsigned)nwg), dim3(64 * NW), lds, st, a2);
+    le = hipGetLastError();
     if (stamp) {
         std::vector<unsigned long long> hbuf(dbg_bytes / 8);
         (void)hipStreamSynchronize(st);
@@ -430,6 +514,15 @@ hipError_t launch_wino_dma_n(ConvKind kind, const ConvArgs &a, hipStream_t st)
 }
 
 }  // namespace
+
+long wino_workgroups(const ConvArgs &a)
+{
+    using G = DmaGeom<4>;
+    const long tilesX = (a.W + G::TPW - 1) / G::TPW;
+    const long gc = a.nct < 8 ? a.nct : 8, gp = G::SUP / gc;
+    const long ptiles = (long)a.N * a.tilesY * tilesX;
+    return ((ptiles + gp - 1) / gp) * gp * a.nct;
+}
 
 hipError_t launch_wino_conv(ConvKind kind, const ConvArgs &a, hipStream_t st)
 {

@@ -488,3 +488,29 @@ def test_forward_is_stream_capturable(net, dev):
         torch.cuda.synchronize()
         again = net(x)
     assert torch.equal(y, again) and not torch.equal(y, ref)
+
+
+@pytest.mark.gpu
+def test_split_k_small_batch_path(dev, weights_np, golden_dir, monkeypatch):
+    """ADN_WINO_SPLITK=1 (serving latency at batch 1-2): deep layers are cut along K into up to 8 workgroups per output
+    tile + a reduce launch.  Same tolerance against the reference goldens; not bit-identical to the default path
+    (different summation order), which is why it is opt-in."""
+    from audiodenoiser_amd.model import UNet
+    from audiodenoiser_amd.weights import make_input
+    monkeypatch.setenv("ADN_WINO_SPLITK", "1")
+    m = UNet(1, 1)
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in weights_np.items()}, strict=True)
+    m = m.to(dev).eval()
+    for (n, f, t) in GOLDEN_SHAPES:
+        g = np.load(os.path.join(golden_dir, f"unet_{f}x{t}.npz"))
+        x = torch.from_numpy(make_input(7, n, f, t)).to(dev)
+        with torch.no_grad():
+            y, taps = m(x, return_taps=True)
+            again = m(x)
+        assert _rel(y.cpu().numpy(), g["y"]) <= TOL, (f, t)
+        assert torch.equal(y, again)                                   # fixed summation order: deterministic
+        for name, tp in taps.items():
+            a = tp.cpu().numpy().astype(np.float64).ravel()
+            s_, sa, sq, cnt = g[f"{name}_stats"]
+            assert np.abs(a[g[f"{name}_idx"]] - g[f"{name}_val"]).max() <= 10 * TOL * np.sqrt(sq / cnt), name
+            assert abs(np.abs(a).sum() - sa) <= TOL * sa, name
