@@ -122,6 +122,11 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
     const int n = pt / p.tilesY;
     const int gy0 = ty * WT - 1, gx0 = tx * G::TPW - 1;
 
+    // The U slab of the first chunk needs no halo plan: its copy starts here and flies under the index arithmetic below.
+    const float *wp = static_cast<const float *>(p.wpk) + ((size_t)ct * p.nchunk + c0) * 4096 + tid * 4;
+#pragma unroll
+    for (int k = HR; k < HR + UR; ++k) dma16(wp + (k - HR) * NT * 4, smem + wave * 256 + k * NT * 4);
+
     // ---- DMA plan: halo slot s = r*NT + tid  ->  (row, pixel, 16-byte part) ----
     // hcur = offsets into the source of the NEXT chunk to copy; hsec = offsets into the second source (virtual
     // concat).  Two plain arrays switched once at chunk nchunk0 (a `first ? a[r] : b[r]` select makes hipcc build
@@ -144,7 +149,6 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
     }
     const float *srcp = static_cast<const float *>(p.s0.ptr) + (size_t)n * p.s0.H * p.s0.W * p.s0.C;   // next chunk's channels
     const float *base1 = static_cast<const float *>(p.s1.ptr) + (size_t)n * p.s1.H * p.s1.W * p.s1.C;
-    const float *wp = static_cast<const float *>(p.wpk) + ((size_t)ct * p.nchunk + c0) * 4096 + tid * 4;
     if (SPLIT) {
         if (c0 >= p.nchunk0) {                            // the slice starts inside the second source (virtual concat)
             srcp = base1 + (size_t)(c0 - p.nchunk0) * WKC;
@@ -222,7 +226,10 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
             tprev = t_;                                                                      \
         }                                                                                    \
     } while (0)
-    ADN_DMA(c0, 0);
+    ADN_DMA_BEGIN(c0);                                 // first chunk: the U pieces were issued at the top
+#pragma unroll
+    for (int k = 0; k < HR; ++k) ADN_DMA_PIECE(k, 0);
+    ADN_DMA_END();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (stamp) {
