@@ -105,7 +105,9 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
 
     // Workgroup -> (pixel tile, cout tile).  After the XCD remap, SUP consecutive ids run together on one XCD;
     // they form a supertile of gc cout tiles x gp pixel tiles so that every U slab and every halo is fetched into
-    // that XCD's L2 once and hit by the other workgroups of the supertile.
+    // that XCD's L2 once and hit by the other workgroups of the supertile.  The two workgroups resident on one CU are
+    // members wl and wl+32 (tools/ubench/placement.hip: block ids 256 apart): with gc = 8 they have the same cout tile,
+    // i.e. the same U slab (an L1 hit for the second); pairing them on the same pixel tile instead measured 1 % slower.
     const int split = SPLIT ? (int)blockIdx.x / p.nwg_base : 0;
     const int nloc = SPLIT ? p.nchunk / p.ksplit : p.nchunk;      // chunks this workgroup sums
     const int c0 = split * nloc;                                   // first of them
