@@ -71,6 +71,17 @@ def load() -> ctypes.CDLL:
         return L
 
 
+def staging_device():
+    """The ROCm device host tensors are staged on when a caller hands CPU tensors to the mirror (the reference's
+    ``test.py`` keeps model and data on the CPU, ``test.py:63-66,100,112-113``): torch's current device.  There is
+    no CPU implementation, so without a device this raises."""
+    import torch
+    if not torch.cuda.is_available():
+        raise AdnError("audiodenoiser_amd: no ROCm device is visible; the hot path has no CPU implementation "
+                       "(CPU tensors are staged onto the current ROCm device, computed there by libadn.so and copied back)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
 def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = load().adn_last_error()

@@ -6,6 +6,7 @@ copied tree with fresh mtimes does not trigger a rebuild.
 """
 from __future__ import annotations
 
+import fcntl
 import glob
 import hashlib
 import os
@@ -19,7 +20,19 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIBDIR = os.path.join(HERE, "_lib")
 LIB = os.path.join(LIBDIR, "libadn.so")
 STAMP = os.path.join(LIBDIR, "libadn.sha256")
+LOCK = os.path.join(LIBDIR, ".build.lock")
 ARCH = "gfx950"
+
+
+def _extra_flags():
+    """``ADN_BUILD_EXPERIMENTS=1`` compiles the timing-experiment switches in (ablations, in-kernel stamps, A/B
+    tilings; ``-DADN_EXPERIMENTS``).  The production library contains none of them."""
+    flags = []
+    if os.environ.get("ADN_BUILD_EXPERIMENTS", "") not in ("", "0"):
+        flags.append("-DADN_EXPERIMENTS")
+        if os.environ.get("ADN_BUILD_STAMPS", "") not in ("", "0"):
+            flags.append("-DADN_WINO_STAMPS")
+    return flags
 
 
 def _sources():
@@ -33,6 +46,7 @@ def _digest() -> str:
         with open(p, "rb") as f:
             h.update(f.read())
     h.update(ARCH.encode())
+    h.update(" ".join(_extra_flags()).encode())
     return h.hexdigest()
 
 
@@ -48,19 +62,36 @@ def up_to_date() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    """Build (or reuse) the library.  Safe to call from several processes at once (one rank per GPU all import the
+    package): an exclusive file lock serialises the builders, the first one compiles into a temporary file and
+    renames it into place, the others find the library up to date when they get the lock."""
     if not force and up_to_date():
         return LIB
-    hipcc = hipcc_path()
-    if hipcc is None:
-        raise RuntimeError("hipcc not found: cannot build libadn.so (ROCm toolchain required)")
     os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-           "-Wno-unused-function", f"-I{INCLUDE}", "-o", LIB] + _sources()
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True)
-    with open(STAMP, "w") as f:
-        f.write(_digest() + "\n")
+    with open(LOCK, "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and up_to_date():
+                return LIB
+            hipcc = hipcc_path()
+            if hipcc is None:
+                raise RuntimeError("hipcc not found: cannot build libadn.so (ROCm toolchain required)")
+            tmp = f"{LIB}.{os.getpid()}.tmp"
+            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
+                   "-Wno-unused-function", f"-I{INCLUDE}"] + _extra_flags() + ["-o", tmp] + _sources()
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            try:
+                subprocess.run(cmd, check=True)
+                os.replace(tmp, LIB)
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+            with open(STAMP + ".tmp", "w") as f:
+                f.write(_digest() + "\n")
+            os.replace(STAMP + ".tmp", STAMP)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
 
 

@@ -31,6 +31,30 @@ int fail_hip(hipError_t e, const char *what)
         if (e_ != hipSuccess) return fail_hip(e_, #call); \
     } while (0)
 
+// Switches the calling thread to `device` for the lifetime of the guard and restores the caller's device on every
+// exit path: no entry point leaves a hidden side effect on the caller's HIP state (adn.h, Conventions).
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int device)
+    {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != device) {
+            err = hipSetDevice(device);
+            switched = err == hipSuccess;
+        }
+    }
+    ~DeviceGuard()
+    {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
+inline bool aligned_to(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
+
 constexpr float BN_EPS = 1e-5f;   // nn.BatchNorm2d default (reference model.py:12,15)
 constexpr int CH[5] = {64, 128, 256, 512, 1024};
 
@@ -263,9 +287,12 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
     if (!make_plan(N, F, T, h->f16, p)) return fail(ADN_ERR_INVALID, "adn_unet_forward: need N>=1, F,T>=16, T<=4094 and F*T<=2^24");
     if (!workspace || ws_bytes < p.total)
         return fail(ADN_ERR_WORKSPACE, "adn_unet_forward: workspace too small (see adn_unet_workspace_bytes)");
-    int cur_dev = -1;
-    ADN_HIP(hipGetDevice(&cur_dev));
-    if (cur_dev != h->device) ADN_HIP(hipSetDevice(h->device));
+    // the activation buffers are carved out of the workspace in 256-byte granules and read with 16-byte LDS-DMA /
+    // b128 accesses; x and y are accessed as single floats
+    if (!aligned_to(workspace, 16)) return fail(ADN_ERR_INVALID, "adn_unet_forward: workspace must be 16-byte aligned");
+    if (!aligned_to(x, 4) || !aligned_to(y, 4)) return fail(ADN_ERR_INVALID, "adn_unet_forward: x and y must be 4-byte aligned");
+    DeviceGuard guard(h->device);
+    if (guard.err != hipSuccess) return fail_hip(guard.err, "hipSetDevice");
 
     char *ws = static_cast<char *>(workspace);      // activations are fp32 or fp16 (h->f16); offsets are bytes
     void *tA = ws + p.tA, *tB = ws + p.tB;
@@ -419,7 +446,8 @@ int adn_unet_create_ex(adn_unet **handle, int device, const float *const *t, int
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(ADN_ERR_NO_DEVICE, "no HIP device visible");
     if (device < 0 || device >= ndev) return fail(ADN_ERR_INVALID, "adn_unet_create: bad device index");
-    ADN_HIP(hipSetDevice(device));
+    DeviceGuard guard(device);
+    if (guard.err != hipSuccess) return fail_hip(guard.err, "hipSetDevice");
     hipDeviceProp_t prop;
     ADN_HIP(hipGetDeviceProperties(&prop, device));
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
@@ -526,7 +554,8 @@ int adn_unet_create_ex(adn_unet **handle, int device, const float *const *t, int
 int adn_unet_set_timing(adn_unet *h, int max_forwards)
 {
     if (!h || max_forwards < 0 || max_forwards > 4096) return fail(ADN_ERR_INVALID, "adn_unet_set_timing: bad argument");
-    ADN_HIP(hipSetDevice(h->device));
+    DeviceGuard guard(h->device);
+    if (guard.err != hipSuccess) return fail_hip(guard.err, "hipSetDevice");
     for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
     h->events.clear();
     h->timing_max = 0;
@@ -540,6 +569,8 @@ int adn_unet_set_timing(adn_unet *h, int max_forwards)
 int adn_unet_get_timing(adn_unet *h, int index, float *ms)
 {
     if (!h || !ms || index < 0 || index >= h->timing_count) return fail(ADN_ERR_INVALID, "adn_unet_get_timing: no such forward");
+    DeviceGuard guard(h->device);
+    if (guard.err != hipSuccess) return fail_hip(guard.err, "hipSetDevice");
     hipEvent_t *ev = h->events.data() + (size_t)index * (ADN_N_LAUNCHES + 1);
     ADN_HIP(hipEventSynchronize(ev[ADN_N_LAUNCHES]));
     for (int k = 0; k < ADN_N_LAUNCHES; ++k) ADN_HIP(hipEventElapsedTime(&ms[k], ev[k], ev[k + 1]));
@@ -549,10 +580,10 @@ int adn_unet_get_timing(adn_unet *h, int index, float *ms)
 int adn_unet_destroy(adn_unet *h)
 {
     if (!h) return ADN_OK;
-    for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
-    if (h->dev) {
-        (void)hipSetDevice(h->device);
-        (void)hipFree(h->dev);
+    {
+        DeviceGuard guard(h->device);
+        for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
+        if (h->dev) (void)hipFree(h->dev);
     }
     delete h;
     return ADN_OK;
@@ -621,7 +652,8 @@ int adn_per_clip_l1(const float *a, const float *b, int n_clips, long elems_per_
 
 int adn_perceptual_loss_workspace_bytes(int n_clips, int F, int T, size_t *bytes)
 {
-    if (!bytes || n_clips < 1 || F < 1 || T < 64) return fail(ADN_ERR_INVALID, "adn_perceptual_loss_workspace_bytes: need n_clips,F >= 1 and T >= 64");
+    if (!bytes || n_clips < 1 || F < 1 || T < 64 || T > adn::ADN_LOSS_MAX_T)
+        return fail(ADN_ERR_INVALID, "adn_perceptual_loss_workspace_bytes: need n_clips,F >= 1 and 64 <= T <= 6784");
     *bytes = adn::perceptual_loss_workspace_floats(n_clips, F, T) * sizeof(float);
     return ADN_OK;
 }
@@ -630,7 +662,9 @@ int adn_perceptual_loss(const float *pred, const float *target, int n_clips, int
                         size_t workspace_bytes, float *out, void *stream)
 {
     if (!pred || !target || !out) return fail(ADN_ERR_INVALID, "adn_perceptual_loss: null pointer");
-    if (n_clips < 1 || F < 1 || T < 64 || T > 6000) return fail(ADN_ERR_INVALID, "adn_perceptual_loss: need n_clips,F >= 1 and 64 <= T <= 6000");
+    if (n_clips < 1 || F < 1 || T < 64 || T > adn::ADN_LOSS_MAX_T || adn::perceptual_loss_lds_bytes(T) > adn::ADN_LOSS_MAX_LDS)
+        return fail(ADN_ERR_INVALID, "adn_perceptual_loss: need n_clips,F >= 1 and 64 <= T <= 6784 (the per-clip series, "
+                                     "trig tables and mel frames of one clip must fit the 160 KiB LDS of a CU)");
     const size_t need = adn::perceptual_loss_workspace_floats(n_clips, F, T) * sizeof(float);
     if (!workspace || workspace_bytes < need) return fail(ADN_ERR_WORKSPACE, "adn_perceptual_loss: workspace too small");
     ADN_HIP(adn::launch_perceptual_loss(pred, target, n_clips, F, T, static_cast<float *>(workspace), out,
@@ -655,6 +689,7 @@ int adn_stft_complex(const float *audio, int n_clips, long length, int n_fft, in
     if (n_clips < 1 || hop < 1 || length < 1 || length >= (1L << 30)) return fail(ADN_ERR_INVALID, "adn_stft_complex: bad sizes");
     const long T = 1 + length / hop;
     if (T > 0x7fffffffL) return fail(ADN_ERR_INVALID, "adn_stft_complex: too many frames");
+    if (!aligned_to(spec_out, 8)) return fail(ADN_ERR_INVALID, "adn_stft_complex: spec_out must be 8-byte aligned");
     ADN_HIP(adn::launch_stft_complex(audio, n_clips, length, n_fft, hop, (int)T, spec_out, static_cast<hipStream_t>(stream)));
     return ADN_OK;
 }
@@ -674,6 +709,7 @@ int adn_istft(const float *spec, int n_clips, int n_frames, int n_fft, int hop, 
         return fail(ADN_ERR_INVALID, "adn_istft: need power-of-two n_fft in [64,4096], n_frames >= 2, 1 <= hop <= n_fft");
     const size_t need = (size_t)n_clips * n_frames * n_fft * sizeof(float);
     if (!workspace || workspace_bytes < need) return fail(ADN_ERR_WORKSPACE, "adn_istft: workspace too small");
+    if (!aligned_to(spec, 8) || !aligned_to(workspace, 8)) return fail(ADN_ERR_INVALID, "adn_istft: spec and workspace must be 8-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
     ADN_HIP(adn::launch_istft_frames(spec, n_clips, n_frames, n_fft, static_cast<float *>(workspace), st));
     ADN_HIP(adn::launch_istft_ola(static_cast<const float *>(workspace), n_clips, n_frames, n_fft, hop, audio_out, st));
@@ -699,6 +735,7 @@ int adn_griffin_lim(const float *magnitude, const float *rnd, int n_clips, int n
     size_t need = 0;
     adn_griffin_lim_workspace_bytes(n_clips, n_bins, n_frames, &need);
     if (!workspace || workspace_bytes < need) return fail(ADN_ERR_WORKSPACE, "adn_griffin_lim: workspace too small");
+    if (!aligned_to(workspace, 8)) return fail(ADN_ERR_INVALID, "adn_griffin_lim: workspace must be 8-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
     float *spec = static_cast<float *>(workspace);
     float *buf = spec + (size_t)n_clips * n_frames * n_bins * 2;

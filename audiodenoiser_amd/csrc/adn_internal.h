@@ -83,6 +83,11 @@ hipError_t launch_stft_complex(const float *audio, int n_clips, long L, int n_ff
 hipError_t launch_quantize_pad(const float *in, int n, int h, int w, float *out, int H, int W, hipStream_t st);
 hipError_t launch_per_clip_l1(const float *a, const float *b, int n_clips, long elems, float *out, hipStream_t st);
 size_t perceptual_loss_workspace_floats(int n_clips, int F, int T);
+// LDS the finishing kernel needs for T frames; the launch is refused above ADN_LOSS_MAX_LDS (160 KiB per CU minus
+// the kernel's static reduction scratch), i.e. T <= ADN_LOSS_MAX_T
+size_t perceptual_loss_lds_bytes(int T);
+constexpr size_t ADN_LOSS_MAX_LDS = 160 * 1024 - 64;
+constexpr int ADN_LOSS_MAX_T = 6784;
 hipError_t launch_perceptual_loss(const float *pred, const float *tgt, int n_clips, int F, int T, float *workspace,
                                   float *out, hipStream_t st);
 

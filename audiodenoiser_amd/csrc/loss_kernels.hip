@@ -216,6 +216,9 @@ hipError_t get_melfb(const float **out)
 
 }  // namespace
 
+// dynamic LDS of loss_finish_kernel: two T-long series, two 64-entry trig tables, 2 x 32 bins x (1 + T/16) mel frames
+size_t perceptual_loss_lds_bytes(int T) { return (size_t)(2 * T + 128 + 2 * 32 * (1 + T / 16)) * sizeof(float); }
+
 size_t perceptual_loss_workspace_floats(int n_clips, int F, int T)
 {
     const int nslab = (F + LOSS_ROWS - 1) / LOSS_ROWS;
@@ -229,13 +232,18 @@ hipError_t launch_perceptual_loss(const float *pred, const float *tgt, int n_cli
     hipError_t e = get_melfb(&fb);
     if (e != hipSuccess) return e;
     const int nslab = (F + LOSS_ROWS - 1) / LOSS_ROWS;
+    // everything that can fail is checked BEFORE the first launch (nothing is enqueued on an error)
+    const size_t lds = perceptual_loss_lds_bytes(T);
+    if (lds > ADN_LOSS_MAX_LDS) return hipErrorInvalidValue;
+    if (lds > 64 * 1024) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(loss_finish_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(loss_colsum_kernel, dim3((unsigned)(n_clips * nslab)), dim3(256), 0, st, pred, tgt, F, T, nslab,
                        workspace);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    const int nfr = 1 + T / 16;
-    const size_t lds = (size_t)(2 * T + 128 + 2 * 32 * nfr) * sizeof(float);
-    if (lds > 64 * 1024) return hipErrorInvalidValue;
     hipLaunchKernelGGL(loss_finish_kernel, dim3((unsigned)n_clips), dim3(256), lds, st, workspace, F, T, nslab, fb, out);
     return hipGetLastError();
 }

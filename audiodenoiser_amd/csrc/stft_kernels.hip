@@ -286,8 +286,14 @@ template <int M, int NW, int FPB, int WPE>
 __global__ __launch_bounds__(NW * 64, WPE) void stft_wave_kernel(const float *__restrict__ audio, long L, int hop, int pad,
                                                              long n_frames, int groups_per_clip, int gpb,
                                                              int blocks_per_clip, const float *__restrict__ tables,
-                                                             float *__restrict__ out, int ablate)
+                                                             float *__restrict__ out, int ablate_arg)
 {
+#ifdef ADN_EXPERIMENTS
+    const int ablate = ablate_arg;              // timing experiments (ADN_STFT_ABLATE): skip loads (1) / stores (2)
+#else
+    constexpr int ablate = 0;
+    (void)ablate_arg;
+#endif
     constexpr int N = 2 * M, TPF = M / 8, NT = NW * 64;
     constexpr int SLOTS = NT / TPF, FPS = FPB / SLOTS;      // frames per slot and group, processed in sequence
     constexpr int MAGSTR = FPB + 1;
@@ -470,6 +476,16 @@ __global__ __launch_bounds__(NW * 64, WPE) void stft_wave_kernel(const float *__
     }
 }
 
+inline int stft_ablate()
+{
+#ifdef ADN_EXPERIMENTS
+    const char *a = std::getenv("ADN_STFT_ABLATE");
+    return a ? std::atoi(a) : 0;
+#else
+    return 0;
+#endif
+}
+
 template <int M, int NW, int FPB, int WPE = 3>
 hipError_t launch_wave(const float *audio, int n_clips, long L, int hop, int pad, long n_frames, const float *tables,
                        float *out, hipStream_t st, int gpb)
@@ -489,7 +505,7 @@ hipError_t launch_wave(const float *audio, int n_clips, long L, int hop, int pad
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(NW * 64), lds, st, audio, L, hop, pad, n_frames, (int)groups,
-                       gpb, (int)bpc, tables, out, []() { const char *a = std::getenv("ADN_STFT_ABLATE"); return a ? std::atoi(a) : 0; }());
+                       gpb, (int)bpc, tables, out, stft_ablate());
     return hipGetLastError();
 }
 
@@ -568,28 +584,37 @@ hipError_t launch_stft_mag(const float *audio, int n_clips, long L, int n_fft, i
     hipError_t e = get_tables(n_fft, &tables);
     if (e != hipSuccess) return e;
     const int pad = center ? n_fft / 2 : 0;
-    // experiment switch (tools/bench_stft.py A/B runs); 0 = workgroup-synchronous kernel, unset = default
+#ifdef ADN_EXPERIMENTS
+    // experiment switches (A/B runs); variant 0 = workgroup-synchronous kernel, unset = default
     const char *ev = std::getenv("ADN_STFT_VARIANT");
     const int variant = ev ? std::atoi(ev) : -1;
     const char *eg = std::getenv("ADN_STFT_GPB");
-    const int gpb = eg ? std::atoi(eg) : 1;               // frame groups per workgroup (1 measured best: no in-loop barriers)
+    const int gpb = eg ? std::atoi(eg) : 1;
+#else
+    constexpr int variant = -1;
+    constexpr int gpb = 1;                                // frame groups per workgroup (1 measured best: no in-loop barriers)
+#endif
     if (variant != 0) {
         switch (n_fft) {
             case 64: return launch_wave<32, 1, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
             case 128: return launch_wave<64, 2, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
             case 256: return launch_wave<128, 4, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
             case 512:
+#ifdef ADN_EXPERIMENTS
                 if (variant == 1) return launch_wave<256, 8, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
                 if (variant == 2) return launch_wave<256, 4, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
                 if (variant == 3) return launch_wave<256, 2, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
                 if (variant == 4) return launch_wave<256, 2, 32>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
+#endif
                 // measured on 10 k x 3 s clips (ms): <8,16> 9.31, <4,16> 5.42, <2,32> 6.08, <2,16> 4.78, <4,32> 4.71
                 return launch_wave<256, 4, 32>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
             case 1024:
+#ifdef ADN_EXPERIMENTS
                 if (variant == 1) return launch_wave<512, 8, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
                 if (variant == 3) return launch_wave<512, 8, 32>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
                 if (variant == 4) return launch_wave<512, 4, 32>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
                 if (variant == 5) return launch_wave<512, 8, 16, 4>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
+#endif
                 return launch_wave<512, 4, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
             default: break;
         }

@@ -211,10 +211,10 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
     const int b_lane = (q * 16 + ti) * 4;                    // U slab [pos/2][j][q][n%16][pos%2][2]
 
     // diagnostic stamps (p.dbg != nullptr only; never in production): cycles per phase, summed over the chunks
-#ifdef ADN_WINO_STAMPS
+#if defined(ADN_EXPERIMENTS) && defined(ADN_WINO_STAMPS)
     const bool stamp = p.dbg != nullptr;
 #else
-    constexpr bool stamp = false;                     // build with -DADN_WINO_STAMPS for the in-kernel phase stamps
+    constexpr bool stamp = false;                     // -DADN_EXPERIMENTS -DADN_WINO_STAMPS: in-kernel phase stamps
 #endif
     unsigned long long tprev = 0, tsum[6] = {0, 0, 0, 0, 0, 0};
 #define ADN_STAMP(k)                                                                         \
@@ -241,7 +241,11 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
         // the copy of chunk c+1 is issued in four slices between the MFMA groups below: a wave stalled in VMEM issue
         // (back-pressure of the CU's ~12 B/clk ingest path) then overlaps its SIMD partner's MFMAs instead of
         // delaying its own
+#ifdef ADN_EXPERIMENTS
         const bool more = c + 1 < nloc && !((p.ablate & 1) && c >= 1);   // ablate&1: timing experiment, no copies
+#else
+        const bool more = c + 1 < nloc;
+#endif
         const int nb = (c + 1) & 1;
         if (more) ADN_DMA_BEGIN(c0 + c + 1);
         ADN_STAMP(0);
@@ -451,7 +455,10 @@ hipError_t launch_wino_dma_n(ConvKind kind, const ConvArgs &a, hipStream_t st)
     const long nwg = ((ptiles + gp - 1) / gp) * gp * a2.nct;
     if (nwg <= 0 || nwg > 0x7fffffffL) return hipErrorInvalidValue;
     if (!a2.zeros) return hipErrorInvalidValue;
+    a2.ablate = 0;
+#ifdef ADN_EXPERIMENTS
     { const char *ab = std::getenv("ADN_WINO_ABLATE"); a2.ablate = ab ? std::atoi(ab) : 0; }   // timing experiments only
+#endif
     // the attribute is per device: remember which devices of this process have it (one process per GPU is the
     // deployment model, but a handle may be created on any device)
     static std::atomic<unsigned long long> attr_mask{0};
@@ -471,7 +478,11 @@ hipError_t launch_wino_dma_n(ConvKind kind, const ConvArgs &a, hipStream_t st)
         attr_mask.fetch_or(bit, std::memory_order_release);
     }
     a2.dbg = nullptr;
+#ifdef ADN_EXPERIMENTS
     const bool stamp = std::getenv("ADN_WINO_STAMP") != nullptr;      // diagnostic path only
+#else
+    constexpr bool stamp = false;
+#endif
     const size_t dbg_bytes = (size_t)nwg * NW * 8 * sizeof(unsigned long long);
     if (stamp) {
         if (hipMalloc(&a2.dbg, dbg_bytes) != hipSuccess) return hipErrorOutOfMemory;
@@ -535,10 +546,13 @@ long wino_workgroups(const ConvArgs &a)
 
 hipError_t launch_wino_conv(ConvKind kind, const ConvArgs &a, hipStream_t st)
 {
+#ifdef ADN_EXPERIMENTS
     // experiment switch ADN_WINO_WAVES=8: one 8-wave workgroup per CU on a 16x32 px tile (fewer staged bytes per
     // MFMA, but measured slower: 197 vs 232 TFLOP/s, its two waves per SIMD run in lockstep)
     static const int waves = []() { const char *e = std::getenv("ADN_WINO_WAVES"); return e ? std::atoi(e) : 4; }();
-    return waves == 8 ? launch_wino_dma_n<8>(kind, a, st) : launch_wino_dma_n<4>(kind, a, st);
+    if (waves == 8) return launch_wino_dma_n<8>(kind, a, st);
+#endif
+    return launch_wino_dma_n<4>(kind, a, st);
 }
 
 }  // namespace adn

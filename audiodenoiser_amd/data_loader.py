@@ -97,9 +97,19 @@ class WavToSpecDataset(Dataset):
       bottom/right zero-pad to ``target_size``, ``(noisy, clean)`` each ``(1, H, W)`` float32.
 
     ``subset_fraction`` keeps the first ``max(1, int(n * fraction))`` pairs of the sorted list (deterministic).
-    The STFT, the quantisation and the crop/pad run on the device (``adn_stft_mag`` + ``adn_quantize_pad``);
-    items come back as host tensors like the reference's datasets, ``load_batch_to_device`` keeps whole batches
-    in HBM for the forward.  No resampling: ``sample_rate`` (if given) is checked against each file.
+    The STFT, the quantisation and the crop/pad run on the device (``adn_stft_mag`` + ``adn_quantize_pad``); there is
+    no host STFT.  That fixes how the dataset is fed to a ``DataLoader`` (reference ``train.py:118-119`` uses
+    ``num_workers=4, pin_memory=True``):
+
+    * ``ds[i]`` (main process, ``num_workers=0``): device STFT, items come back as host tensors like the reference's
+      datasets.  Inside a DataLoader WORKER process it raises: workers are forked from a parent that has already
+      initialised HIP (``model.to(DEVICE)``, ``train.py:122``) and a forked child cannot use the GPU.
+    * ``DataLoader(ds.audio_view(clip_samples), num_workers=4, collate_fn=ds.collate_to_device)``: the workers only
+      decode wav files (host I/O) and hand back fixed-length audio; the main process runs ONE batched device STFT per
+      batch and yields ``(noisy, clean)`` batches ``(B, 1, H, W)`` already resident in HBM -- the MI355X-shaped feed.
+    * ``load_batch_to_device(indices)``: the same without a DataLoader.
+
+    No resampling: ``sample_rate`` (if given) is checked against each file.
     """
 
     def __init__(self, data_dir, subset_fraction: float = 1.0, target_size=(256, 64), n_fft: int = 512,
@@ -127,12 +137,18 @@ class WavToSpecDataset(Dataset):
         return audio
 
     def _spec_batch(self, audios):
-        """list of equally long 1-D float32 arrays -> (B, 1, H, W) float32 on the device."""
+        """(B, L) float32 audio (array, list of equally long arrays, or tensor) -> (B, 1, H, W) float32 on the device."""
         from .stft import stft_magnitude
-        a = torch.from_numpy(np.stack(audios)).to(self.device)
+        a = audios if isinstance(audios, torch.Tensor) else torch.from_numpy(np.stack(audios))
+        a = a.to(self.device, non_blocking=True)
         return quantize_pad_on_device(stft_magnitude(a, self.n_fft, self.hop_length, True), self.target_size)
 
     def __getitem__(self, idx):
+        if torch.utils.data.get_worker_info() is not None:
+            raise RuntimeError(
+                "WavToSpecDataset computes its spectrograms on the GPU (there is no host STFT) and a DataLoader worker "
+                "process forked from a GPU-initialised parent cannot use HIP.  Use num_workers=0, or let the workers "
+                "decode audio only: DataLoader(ds.audio_view(clip_samples), num_workers=4, collate_fn=ds.collate_to_device)")
         noisy_path, clean_path = self.pairs[idx]
         noisy, clean = self._audio(noisy_path), self._audio(clean_path)
         if len(noisy) == len(clean):
@@ -145,3 +161,36 @@ class WavToSpecDataset(Dataset):
         noisy = [self._audio(self.pairs[i][0]) for i in indices]
         clean = [self._audio(self.pairs[i][1]) for i in indices]
         return self._spec_batch(noisy), self._spec_batch(clean)
+
+    # ---- DataLoader feed: host-only items, device collate ------------------------------------------------
+    def audio_view(self, clip_samples: int):
+        """Host-only ``Dataset`` of ``(noisy_audio, clean_audio)`` float32 tensors cropped / zero-padded at the end to
+        ``clip_samples`` -- safe in DataLoader worker processes (wav decoding only, no GPU)."""
+        return _WavAudioView(self, int(clip_samples))
+
+    def collate_to_device(self, batch):
+        """``collate_fn`` for :meth:`audio_view`: runs in the DataLoader's main process; one batched device STFT +
+        quantise + crop/pad per side -> ``(noisy, clean)`` each ``(B, 1, H, W)`` float32 on the device."""
+        noisy = torch.stack([b[0] for b in batch])
+        clean = torch.stack([b[1] for b in batch])
+        return self._spec_batch(noisy), self._spec_batch(clean)
+
+
+class _WavAudioView(Dataset):
+    def __init__(self, parent: "WavToSpecDataset", clip_samples: int):
+        if clip_samples < parent.n_fft // 2 + 1:
+            raise ValueError("clip_samples too short for one centred STFT frame")
+        self.parent, self.clip_samples = parent, clip_samples
+
+    def __len__(self):
+        return len(self.parent)
+
+    def _fit(self, audio):
+        out = np.zeros(self.clip_samples, dtype=np.float32)
+        n = min(self.clip_samples, len(audio))
+        out[:n] = audio[:n]
+        return torch.from_numpy(out)
+
+    def __getitem__(self, idx):
+        noisy_path, clean_path = self.parent.pairs[idx]
+        return self._fit(self.parent._audio(noisy_path)), self._fit(self.parent._audio(clean_path))

@@ -1,7 +1,11 @@
-"""Per-clip L1 on the device: the value each rank contributes to the multi-GPU all-gather.
+"""Per-clip losses on the device: the values each rank contributes to the multi-GPU all-gather and
+the mirror of the reference's ``loss.CombinedPerceptualLoss`` (``/root/reference/code/loss.py:6-95``).
 
 ``per_clip_l1(a, b)[i] = mean |a[i] - b[i]|``; clips have equal sizes, so the mean over clips equals the batch
-``F.l1_loss`` term of the reference's ``CombinedPerceptualLoss`` (``/root/reference/code/loss.py:86``).
+``F.l1_loss`` term of the reference's ``CombinedPerceptualLoss`` (``loss.py:86``).
+
+CPU tensors (the reference's ``test.py:118-122`` builds its loss inputs on the CPU) are staged onto the current ROCm
+device, computed there and the result is returned on the inputs' device; without a device every call raises.
 """
 from __future__ import annotations
 
@@ -28,9 +32,13 @@ def per_clip_l1(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 def perceptual_loss_per_clip(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
     """(B,1,F,T) x2 on a ROCm device -> (B,4) = [total, stft, mel, l1] per clip (reference ``loss.py:6-95``)."""
     import ctypes
-    if (pred.shape != target.shape or pred.dim() != 4 or pred.shape[1] != 1 or not pred.is_cuda or not target.is_cuda
+    if (pred.shape != target.shape or pred.dim() != 4 or pred.shape[1] != 1 or pred.device != target.device
             or pred.dtype != torch.float32 or target.dtype != torch.float32):
-        raise ValueError("perceptual_loss_per_clip: expected two (B,1,F,T) float32 tensors on a ROCm device")
+        raise ValueError("perceptual_loss_per_clip: expected two (B,1,F,T) float32 tensors on one device")
+    home = pred.device
+    if not pred.is_cuda:                                   # test.py:118-122: CPU tensors -> staged, HIP path, back
+        dev = _lib.staging_device()
+        return perceptual_loss_per_clip(pred.to(dev), target.to(dev)).to(home)
     pred = pred.contiguous()
     target = target.contiguous()
     b, _, f, t = pred.shape

@@ -6,9 +6,12 @@ reference checkpoint, ``test.py:65``), and ``forward(x: (N,1,F,T) float32) -> (N
 (``model.py:70-94``).  The arithmetic does NOT go through ATen: ``forward`` hands raw device pointers and the
 current PyTorch-ROCm stream to ``libadn.so`` (``include/adn.h``).
 
-Scope: the inference forward — eval mode, no autograd, CUDA/ROCm tensors.  Train-mode forward
-(batch-statistics BatchNorm + backward, reference ``train.py:62-71``) and CPU tensors are outside the
-accelerated path and raise; nothing falls back silently.
+Scope: the inference forward — eval mode, no autograd.  The reference's own caller keeps the model
+and its input on the CPU (``test.py:63-66,100,112-113``); such a call is served by the same HIP path: the input is
+staged onto the current ROCm device, the packed weights are uploaded from wherever the parameters live, and the
+result comes back on the input's device.  Train-mode forward (batch-statistics BatchNorm + backward, reference
+``train.py:62-71``) raises, and so does any call on a machine without a ROCm device; nothing falls back to CPU
+arithmetic.
 """
 from __future__ import annotations
 
@@ -158,9 +161,6 @@ class UNet(nn.Module):
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             raise RuntimeError("audiodenoiser_amd.UNet: the HIP forward records no autograd graph; wrap the call in "
                                "torch.no_grad() as the reference's test.py:112 / train.py:80 do")
-        if not x.is_cuda:
-            raise RuntimeError("audiodenoiser_amd.UNet: input must live on a ROCm device (no CPU path; "
-                               "move model and input with .to('cuda'))")
         if x.dim() != 4 or x.shape[1] != 1:
             raise ValueError(f"expected input (N, 1, F, T), got {tuple(x.shape)}")
         if x.shape[2] < 16 or x.shape[3] < 16:
@@ -170,6 +170,11 @@ class UNet(nn.Module):
 
     def forward(self, x: torch.Tensor, return_taps: bool = False):
         self._check_input(x)
+        home = x.device
+        if not x.is_cuda:
+            # the reference's test.py call shape: CPU tensor into a model that was never moved.  Stage on the current
+            # ROCm device (raises when there is none) -- still the HIP path, no CPU arithmetic.
+            x = x.to(_lib.staging_device())
         x = x.contiguous()
         n, _, f, t = x.shape
         dev = x.device
@@ -182,7 +187,7 @@ class UNet(nn.Module):
             if not return_taps:
                 _lib.check(L.adn_unet_forward(handle, x.data_ptr(), y.data_ptr(), n, f, t, ws.data_ptr(), ws.numel(),
                                               stream), "adn_unet_forward")
-                return y
+                return y if home == dev else y.to(home)
             names = ("down1", "down2", "down3", "down4", "bottleneck", "up1", "up2", "up3", "up4", "out")
             ch = (64, 128, 256, 512, 1024)
             hs, wsz = [f], [t]
@@ -195,4 +200,6 @@ class UNet(nn.Module):
             arr = (ctypes.c_void_p * 10)(*[tp.data_ptr() for tp in taps])
             _lib.check(L.adn_unet_forward_taps(handle, x.data_ptr(), y.data_ptr(), n, f, t, ws.data_ptr(), ws.numel(),
                                                arr, stream), "adn_unet_forward_taps")
+            if home != dev:
+                return y.to(home), {k: v.to(home) for k, v in zip(names, taps)}
             return y, dict(zip(names, taps))

@@ -16,7 +16,11 @@
  *     adn_unet_create / adn_unet_destroy (one-time weight upload / free).
  *   - ownership: the caller owns every buffer it passes (x, y, audio, out, workspace); a handle owns only
  *     its packed (BatchNorm-folded, re-laid-out) weights.
- *   - a handle is bound to one device and is not re-entrant: one forward at a time per handle.
+ *   - a handle is bound to one device and is not re-entrant: one forward at a time per handle.  Entry points that
+ *     take a handle run on the handle's device and restore the caller's current device before returning; the
+ *     handle-free entry points (STFT, loader, losses, Griffin-Lim) run on the caller's current device.
+ *   - alignment: workspaces 16 bytes; complex spectrograms (float pairs) 8 bytes; everything else 4 bytes
+ *     (ADN_ERR_INVALID otherwise).  Any hipMalloc / PyTorch allocation satisfies this.
  *   - there is NO CPU implementation in this library.
  */
 #ifndef ADN_H
@@ -109,7 +113,10 @@ int adn_per_clip_l1(const float *a, const float *b, int n_clips, long elems_per_
  * calls (code/loss.py:6-95; caller code/test.py:118-122).  pred, target: (n_clips,1,F,T) fp32 device tensors;
  * out: (n_clips,4) = {total, stft, mel, l1}.  The reference's batch values are the means over clips (equal clip
  * sizes).  Constants are the reference's: scales (63,16),(32,8),(16,4); mel: sr 8000, n_fft 63, hop 16, 64 mels;
- * weights 0.4/0.4/0.2.  Needs T >= 64 and adn_perceptual_loss_workspace_bytes of device scratch. */
+ * weights 0.4/0.4/0.2.  Needs 64 <= T <= ADN_LOSS_MAX_FRAMES (one clip's frequency-mean series, trig tables and mel
+ * frames are held in the 160 KiB LDS of one CU; ADN_ERR_INVALID outside, before anything is enqueued) and
+ * adn_perceptual_loss_workspace_bytes of device scratch. */
+#define ADN_LOSS_MAX_FRAMES 6784
 int adn_perceptual_loss_workspace_bytes(int n_clips, int F, int T, size_t *bytes);
 int adn_perceptual_loss(const float *pred, const float *target, int n_clips, int F, int T, void *workspace,
                         size_t workspace_bytes, float *out, void *stream);

@@ -247,6 +247,66 @@ def test_wav_dataset_discovery_and_subset(tmp_path, capsys):
         WavToSpecDataset(str(tmp_path))
 
 
+def test_wav_dataset_worker_guard_and_audio_view(tmp_path):
+    """train.py:118-119 wraps the dataset in DataLoader(num_workers=4): __getitem__ needs the GPU, so inside a worker
+    it must fail with a clear message (not hang on a forked HIP context); the audio view is host-only and works in
+    workers, its collate runs the device STFT in the main process."""
+    from torch.utils.data import DataLoader
+    from audiodenoiser_amd.data_loader import WavToSpecDataset
+    from audiodenoiser_amd.wav import write_wav
+    rng = np.random.default_rng(2)
+    for i, n in enumerate((900, 1200, 700, 1000)):
+        write_wav(str(tmp_path / f"clean_{i}.wav"), rng.uniform(-1, 1, n).astype(np.float32), 8000, "FLOAT")
+        write_wav(str(tmp_path / f"noisy_{i}.wav"), rng.uniform(-1, 1, n).astype(np.float32), 8000, "FLOAT")
+    ds = WavToSpecDataset(str(tmp_path), sample_rate=8000)
+    with pytest.raises(RuntimeError, match="DataLoader worker"):
+        next(iter(DataLoader(ds, batch_size=2, num_workers=1)))
+    view = ds.audio_view(1000)
+    assert len(view) == 4
+    batches = list(DataLoader(view, batch_size=2, num_workers=2))
+    assert len(batches) == 2
+    for noisy, clean in batches:
+        assert noisy.shape == clean.shape == (2, 1000) and noisy.dtype == torch.float32
+    n0, _ = view[0]                                       # 900 samples -> zero padded at the end
+    assert float(n0[900:].abs().max()) == 0.0 and float(n0[:900].abs().max()) > 0.0
+    n1, _ = view[1]                                       # 1200 samples -> cropped
+    from audiodenoiser_amd.wav import read_wav
+    assert np.array_equal(n1.numpy(), read_wav(str(tmp_path / "noisy_1.wav"))[0][:1000])
+    with pytest.raises(ValueError):
+        ds.audio_view(100)
+
+
+def test_cpu_tensors_without_a_device_raise_instead_of_computing(weights_np):
+    """test.py hands CPU tensors to a CPU-resident model; the mirror stages them on the current ROCm device.  On a
+    machine with no device that must raise -- there is no CPU arithmetic anywhere in the product path."""
+    if torch.cuda.is_available():
+        pytest.skip("this box has a ROCm device; covered by the -m gpu drop-in test")
+    from audiodenoiser_amd._lib import AdnError
+    from audiodenoiser_amd.loss import CombinedPerceptualLoss
+    from audiodenoiser_amd.model import UNet
+    m = UNet(1, 1).eval()
+    with torch.no_grad(), pytest.raises(AdnError, match="no ROCm device"):
+        m(torch.zeros(1, 1, 16, 16))
+    with torch.no_grad(), pytest.raises(AdnError, match="no ROCm device"):
+        CombinedPerceptualLoss()(torch.zeros(1, 1, 16, 64), torch.zeros(1, 1, 16, 64))
+
+
+def test_perceptual_loss_frame_limit_is_reported_before_any_launch():
+    from audiodenoiser_amd import _lib
+    L = _lib.load()
+    header = open(os.path.join(ROOT, "include", "adn.h")).read()
+    tmax = int(re.search(r"#define ADN_LOSS_MAX_FRAMES (\d+)", header).group(1))
+    need = ctypes.c_size_t()
+    assert L.adn_perceptual_loss_workspace_bytes(2, 513, tmax, ctypes.byref(need)) == 0
+    assert need.value == 2 * 17 * (2 * tmax + 1) * 4
+    assert L.adn_perceptual_loss_workspace_bytes(2, 513, tmax + 1, ctypes.byref(need)) == 1
+    buf = (ctypes.c_float * 16)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert L.adn_perceptual_loss(p, p, 1, 64, tmax + 1, p, 1 << 40, p, None) == 1     # rejected on the host
+    assert b"6784" in L.adn_last_error()
+    assert L.adn_perceptual_loss(p, p, 1, 64, 63, p, 1 << 40, p, None) == 1
+
+
 def test_compat_modules_resolve_reference_import_names():
     """PYTHONPATH=compat: the reference's `from model import UNet` etc. pick up the MI355X mirror."""
     import importlib.util

@@ -88,3 +88,26 @@ def test_loader_quantize_pad_matches_reference(golden_dir):
             assert ref.shape == (1,) + target
             assert np.array_equal(got, ref[0]), (ci, key)
         assert np.isinf(g[f"case{ci}_noisy"][0, 0, 0]) and g[f"case{ci}_noisy"][0, 0, 1] == 0.0
+
+
+def _real_clip(golden_dir):
+    fx = np.load(os.path.join(golden_dir, "real_audio_17480-2-0-24.npz"))
+    assert int(fx["sample_rate"]) == 44100 and fx["lr_sum_int16"].shape == (132300,)
+    return fx["lr_sum_int16"].astype(np.float32) / np.float32(65536.0)      # mean(L, R) / 32768, exact in fp32
+
+
+def test_config0_real_audio_oracle_chain_matches_reference_golden(golden_dir, weights_np):
+    """BASELINE configs[0] on the bundled real clip (tools/make_real_audio_fixture.py): oracle STFT 1024/256 centred
+    -> loader rule -> forward.  The loader and forward stages are pinned by config0_real_audio.npz, which the
+    reference's own data_loader.py + model.py produced from the same STFT (tools/make_golden.py --only config0); the
+    STFT stage is parity unpinned (librosa absent) and cross-checked in tests/test_stft_oracle.py."""
+    g = np.load(os.path.join(golden_dir, "config0_real_audio.npz"))
+    clip = _real_clip(golden_dir)
+    assert 0.1 < np.abs(clip).max() < 0.2 and clip.std() < 0.02            # quiet real recording, 21 dB crest factor
+    mag = oracle.stft_mag(clip, 1024, 256, True)
+    assert mag.shape == (513, 517)
+    x = oracle.quantize_pad(mag, (513, 256))
+    assert np.array_equal(x, g["x_f16"].astype(np.float32))                # loader rule, bit exact
+    sd = unet_torch.to_torch_state(weights_np)
+    y = unet_torch.unet_forward(sd, torch.from_numpy(x[None, None])).numpy()[0, 0]
+    assert np.abs(y - g["y"]).max() <= 1e-6 * np.abs(g["y"]).max()

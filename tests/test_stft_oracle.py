@@ -35,6 +35,30 @@ def test_c_vs_numpy_vs_torch(L, n_fft, hop, center):
     assert np.abs(c - t).max() <= 2e-6 * scale
 
 
+def test_real_audio_and_degenerate_signals(golden_dir):
+    """The bundled real clip (quiet, wide dynamic range), silence, a DC offset and a clip with leading silence: C
+    restatement vs the numpy restatement vs torch.stft at BASELINE's n_fft 1024 / hop 256, centred."""
+    import os
+    fx = np.load(os.path.join(golden_dir, "real_audio_17480-2-0-24.npz"))
+    clip = fx["lr_sum_int16"].astype(np.float32) / np.float32(65536.0)
+    gapped = clip.copy()
+    gapped[:30000] = 0.0
+    for a in (clip, gapped, clip + np.float32(0.25)):
+        c = oracle.stft_mag(a, 1024, 256, True)
+        npy = stft_numpy.stft_mag(a, 1024, 256, True)
+        scale = np.abs(npy).max()
+        assert c.shape == (513, 517) and np.abs(c - npy).max() <= 3e-7 * scale
+        t = torch.stft(torch.from_numpy(a), 1024, hop_length=256, win_length=1024,
+                       window=torch.hann_window(1024, periodic=True), center=True, pad_mode="constant",
+                       return_complex=True).abs().numpy()
+        assert np.abs(c - t).max() <= 2e-6 * scale
+    assert not oracle.stft_mag(np.zeros(132300, np.float32), 1024, 256, True).any()          # silence -> exact zeros
+    assert not oracle.stft_mag(gapped, 1024, 256, True)[:, :100].any()                       # frames inside the gap
+    dc = oracle.stft_mag(np.full(8192, 0.5, np.float32), 1024, 256, True)
+    assert np.allclose(dc[0, 4:-4], 0.5 * 512, rtol=1e-6) and np.allclose(dc[1, 4:-4], 0.5 * 256, rtol=1e-6)
+    assert dc[2:, 4:-4].max() < 1e-4
+
+
 def test_reference_shapes():
     assert oracle.stft_mag(np.zeros(16000, np.float32), 512, 128, False).shape == (257, 122)
     assert oracle.stft_mag(np.zeros(24000, np.float32), 512, 128, True).shape == (257, 188)

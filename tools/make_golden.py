@@ -13,6 +13,10 @@ What is frozen:
   (sum, sum|.|, sum of squares) plus 512 sampled elements at hash-chosen flat indices.
 * ``loader_cases.npz`` — ``data_loader.SpectrogramDataset`` (reference ``code/data_loader.py:37-72``) run on
   temporary .npy files: fp16 round trip + crop/pad for four (shape, target_size) cases.
+* ``config0_real_audio.npz`` (``--only config0``) — BASELINE configs[0] on REAL audio: the 3 s clip frozen by
+  ``tools/make_real_audio_fixture.py`` -> STFT 1024/256 centred (CPU oracle; librosa is absent, that stage is parity
+  unpinned) saved as .npy -> the reference's ``SpectrogramDataset(target_size=(513, 256))`` -> the reference's
+  ``UNet.forward``.  Stored: ``x_f16`` (the loader's output, exactly representable in fp16) and ``y``.
 """
 from __future__ import annotations
 
@@ -45,7 +49,37 @@ def sample_indices(name: str, numel: int) -> np.ndarray:
     return np.minimum((u * numel).astype(np.int64), numel - 1)
 
 
+def config0_real_audio() -> None:
+    import data_loader as ref_loader  # reference code/data_loader.py
+    import model as ref_model  # reference code/model.py
+    import oracle
+
+    fx = np.load(os.path.join(GOLDEN, "real_audio_17480-2-0-24.npz"))
+    clip = fx["lr_sum_int16"].astype(np.float32) / np.float32(65536.0)          # mono mix, exact
+    mag = oracle.stft_mag(clip, 1024, 256, True)                                 # (513, 517)
+    torch.set_num_threads(os.cpu_count() or 1)
+    net = ref_model.UNet(in_channels=1, num_classes=1)
+    net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in make_state_dict(WEIGHT_SEED).items()}, strict=True)
+    net.eval()
+    with tempfile.TemporaryDirectory() as d:
+        np.save(os.path.join(d, "noisy_real_chunk_0.npy"), mag)
+        np.save(os.path.join(d, "clean_real_chunk_0.npy"), mag)
+        with contextlib.redirect_stdout(io.StringIO()):
+            ds = ref_loader.SpectrogramDataset(d, target_size=(513, 256))
+        x, _ = ds[0]                                                             # (1, 513, 256) fp32(fp16(.))
+    assert np.array_equal(x.numpy().astype(np.float16).astype(np.float32), x.numpy())
+    with torch.no_grad():
+        y = net(x[None])
+    path = os.path.join(GOLDEN, "config0_real_audio.npz")
+    np.savez_compressed(path, x_f16=x.numpy()[0].astype(np.float16), y=y.numpy()[0, 0].astype(np.float32),
+                        weight_seed=np.array(WEIGHT_SEED))
+    print(f"wrote {path} ({os.path.getsize(path)} bytes): x max {float(x.max()):.3f}, y mean {float(y.mean()):+.4f} "
+          f"std {float(y.std()):.4f}")
+
+
 def main() -> None:
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "config0":
+        return config0_real_audio()
     import data_loader as ref_loader  # reference code/data_loader.py
     import model as ref_model  # reference code/model.py
 
@@ -108,6 +142,7 @@ def main() -> None:
     path = os.path.join(GOLDEN, "loader_cases.npz")
     np.savez_compressed(path, **rec)
     print("wrote", path)
+    config0_real_audio()
 
 
 if __name__ == "__main__":

@@ -66,7 +66,7 @@ def run_noise_type(nt, data_dir, models_dir, out_dir, dev, n_audio=5):
         total, stft, mel, l1 = CombinedPerceptualLoss()(denoised, clean)         # test.py:118-122
     k = min(n_audio, len(noisy))
     noisy_audio = griffin_lim_reconstruction(noisy[:k, 0], N_FFT, HOP)           # test.py:103-109
-    den_audio = griffin_lim_reconstruction(denoised[:k, 0].clamp_min(0), N_FFT, HOP)
+    den_audio = griffin_lim_reconstruction(denoised[:k, 0], N_FFT, HOP)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     for i in range(k):
