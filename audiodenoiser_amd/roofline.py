@@ -8,7 +8,33 @@ fp32 activation traffic per 513x256 sample, + 124.12 MB of weights once per laun
 from __future__ import annotations
 
 PEAK_MFMA_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: 256 CU x 2.4 GHz x 256 FLOP/clk, v_mfma_f32_32x32x2_f32
+PEAK_MFMA_F16_TFLOPS = 2516.6  # dense fp16 MFMA (16x the fp32 rate), MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0          # HBM3E spec; ~6.3 TB/s achievable
+
+
+def _ceil_to(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+def executed_mfma_flops(launch: dict, algo: str) -> float:
+    """Matrix-core FLOPs one launch EXECUTES per sample, padded tiles counted (what `roofline.frac` is made of).
+
+    ``algo``: "winograd" (wino_conv_dma_f32: 16x16-pixel tiles, F(2x2,3x3) = 16 multiply-adds per 2x2 output tile and
+    (cin, cout) pair instead of 36, i.e. 8 FLOP per padded output pixel and channel pair), "direct" (conv_mfma<float>:
+    TH x 16 tiles with TH = 16 for the 64-channel layers and 8 otherwise) or "direct_f16" (conv_mfma<_Float16>: tiles
+    twice as tall).  Transposed convolutions always run the direct kernel: K = Cin, 4*Cout GEMM columns, tiles of
+    input pixels.  The first (Cin = 1) and last (1x1, Cout = 1) layers do not use the matrix cores: 0."""
+    kind = launch["kind"]
+    if kind in ("first", "out"):
+        return 0.0
+    cin, cout, h, w = launch["cin"], launch["cout"], launch["h"], launch["w"]
+    th2 = 2 if algo == "direct_f16" else 1
+    if kind == "convt":
+        return 2.0 * cin * 4 * cout * _ceil_to(h, 8 * th2) * _ceil_to(w, 16)
+    if algo == "winograd":
+        return 8.0 * cin * cout * _ceil_to(h, 16) * _ceil_to(w, 16)
+    th = (16 if cout == 64 else 8) * th2
+    return 18.0 * cin * cout * _ceil_to(h, th) * _ceil_to(w, 16)
 
 
 def unet_launches(f: int, t: int):
@@ -30,7 +56,7 @@ def unet_launches(f: int, t: int):
         if pool:
             act += 4.0 * cout * (h // 2) * (w // 2)
         wb = 4.0 * (cin * cout * k * k + cout)
-        out.append(dict(name=name, kind=kind, flops=flops, act_bytes=act, weight_bytes=wb))
+        out.append(dict(name=name, kind=kind, flops=flops, act_bytes=act, weight_bytes=wb, cin=cin, cout=cout, h=h, w=w))
 
     conv("down1.conv1", "first", 1, 64, hs[0], ws[0], 3)
     conv("down1.conv2+pool", "conv3x3", 64, 64, hs[0], ws[0], 3, pool=True)

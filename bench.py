@@ -5,19 +5,30 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A step = one forward of the hot path over one resident batch per GPU (BASELINE configs[1]: batch 64 of
-synthetic 513x256 fp32 spectrograms) + the per-clip CombinedPerceptualLoss kernels, and for N > 1 the one RCCL
-all-gather of the per-clip values (4 floats per clip) (clips shard over ranks, weights replicated, no data-path collective; weak scaling: the batch
-per GPU is fixed).  Rank 0 prints ONE JSON line; `value` = all ranks' frames / max-over-ranks time.
+A step = one forward of the hot path over one resident batch per GPU (BASELINE configs[1]: batch 64 of synthetic
+513x256 fp32 spectrograms) + the per-clip CombinedPerceptualLoss kernels, and for N > 1 the one RCCL all-gather of
+the per-clip values (4 floats per clip).  Clips shard over ranks, weights are replicated, there is no data-path
+collective; weak scaling: the batch per GPU is fixed.  Rank 0 prints ONE JSON line; `value` = all ranks' frames /
+max-over-ranks time between barrier + synchronize pairs.
 
-roofline: the dominant kernel is wino_conv_dma_f32 (the 17 3x3 convolutions, 95 % of the FLOPs; Winograd
-F(2x2,3x3) on the fp32 matrix cores; ADN_CONV_ALGO=direct selects the direct implicit-GEMM kernel conv_mfma_f32).
-Its launches are bracketed with hipEvents on the launch stream inside libadn (adn_unet_set_timing) during the timed
-steps; achieved = ALGORITHMIC (direct-convolution) FLOPs of those launches / their summed duration (= average
-FLOPs per launch / average launch duration), peak = 157.3 TFLOP/s (fp32 MFMA, MI355X_MICROARCH.md).  Winograd
-executes 1/2.25 of the algorithmic FLOPs on the matrix cores, so `frac` may exceed 1; `mfma_util` is the share of
-the matrix-core peak actually executed.  `traffic` (HBM bytes per launch from rocprofv3 PMC passes) is read from
-profiles/pmc_traffic.json when that file has been produced.
+roofline (dominant kernel = the 17 3x3 convolutions, 95 % of the FLOPs; wino_conv_dma_f32, Winograd F(2x2,3x3) on the
+exact-fp32 matrix cores; ADN_CONV_ALGO=direct selects the direct implicit-GEMM kernel conv_mfma<float>):
+  every launch of the timed steps is bracketed with hipEvents on the launch stream inside libadn
+  (adn_unet_set_timing).  `achieved` = matrix-core FLOPs the kernel EXECUTES per launch (padded tiles counted;
+  Winograd needs 16 multiply-adds per 2x2 output tile and channel pair, audiodenoiser_amd/roofline.py) / average
+  launch duration; `peak` = 157.3 TFLOP/s dense fp32 MFMA (MI355X_MICROARCH.md); `frac` = achieved / peak <= 1.
+  The ALGORITHMIC (direct-convolution) rate of the same launches is under `algorithmic`; it may
+  exceed the direct-convolution roof because Winograd executes 1/2.25 of those FLOPs.
+  `traffic` = HBM bytes per launch from two separate rocprofv3 --pmc passes (2 x FETCH_SIZE + WRITE_SIZE, gfx950
+  correction), read from profiles/pmc_traffic.json ONLY if that file was produced from this very build of libadn.so
+  (source digest recorded in it); null otherwise.
+
+Sub-benchmarks in the same JSON line (rank 0, N = 1 only; --no-extras skips them):
+  `stft`  BASELINE configs[2]: 10 000 clips x 132 300 samples, n_fft 1024, hop 256, centred; HBM roofline of
+          stft_wave_kernel (algorithmic bytes = audio read once + magnitudes written once = 1 590 084 B per clip),
+          with the C oracle's STFT timed beside it.
+  `f16`   BASELINE configs[4]: the same forward at batch 256 with fp16 storage + fp16 MFMA; MFMA roofline of
+          conv_mfma<_Float16> against the dense fp16 peak.
 
 cpu_baseline: the oracle's torch.nn.functional restatement of the reference forward (same ATen/oneDNN kernels
 the reference's model.py dispatches to; kind "port") timed on this host's cores on a bounded sample.
@@ -25,7 +36,6 @@ the reference's model.py dispatches to; kind "port") timed on this host's cores 
 from __future__ import annotations
 
 import argparse
-import ctypes
 import json
 import os
 import sys
@@ -95,26 +105,203 @@ def cpu_baseline(sd_np, budget_s: float = 12.0):
                       "the kernels the reference's model.py dispatches to"}
 
 
+def lib_digest() -> str:
+    from audiodenoiser_amd import build as B
+    try:
+        with open(B.STAMP) as fh:
+            return fh.read().strip()
+    except OSError:
+        return ""
+
+
+def tracked_traffic(kernel_key: str):
+    """HBM bytes per launch of `kernel_key` from profiles/pmc_traffic.json if (and only if) that profile was taken
+    with the library that is being benchmarked now."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            rec = json.load(fh)
+    except (OSError, ValueError):
+        return None, "profiles/pmc_traffic.json missing"
+    if rec.get("lib_digest") != lib_digest():
+        return None, "profiles/pmc_traffic.json was taken with another build of libadn.so (digest differs)"
+    ent = rec.get("kernels", {}).get(kernel_key)
+    if not ent:
+        return None, f"no PMC entry for {kernel_key}"
+    return ent["bytes_per_launch"], (f"profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                     f"`{ent.get('cmd', '?')}` with this build (digest {rec['lib_digest'][:12]})")
+
+
+def make_net(sd_np, dev, dtype):
+    from audiodenoiser_amd.model import UNet
+    net = UNet(1, 1)
+    net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd_np.items()}, strict=True)
+    return net.to(dev).eval().set_compute_dtype(dtype)
+
+
+def launch_timings(net, steps):
+    from audiodenoiser_amd import _lib
+    L = _lib.load()
+    ms = np.zeros((steps, 23), dtype=np.float32)
+    for i in range(steps):
+        _lib.check(L.adn_unet_get_timing(net._handle, i, ms[i].ctypes.data_as(_lib.c_float_p)), "adn_unet_get_timing")
+    _lib.check(L.adn_unet_set_timing(net._handle, 0), "adn_unet_set_timing")
+    return ms.mean(axis=0)
+
+
+def conv_roofline(ms_mean, b, algo, peak, kernel_name, traffic_key):
+    """MFMA roofline of the 17 3x3 launches from their event-timed durations (see the module docstring)."""
+    from audiodenoiser_amd.roofline import executed_mfma_flops, unet_launches
+    launches = unet_launches(F_BINS, T_FRAMES)
+    dom = [i for i, l in enumerate(launches) if l["kind"] == "conv3x3"]
+    dom_ms = float(ms_mean[dom].sum())
+    executed = sum(executed_mfma_flops(launches[i], algo) for i in dom) * b
+    algorithmic = sum(launches[i]["flops"] for i in dom) * b
+    ach = executed / (dom_ms * 1e-3) / 1e12
+    alg = algorithmic / (dom_ms * 1e-3) / 1e12
+    traffic, source = tracked_traffic(traffic_key)
+    return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+            "traffic": traffic, "traffic_source": source,
+            "kernel": f"{kernel_name}, {len(dom)} launches per forward",
+            "achieved_basis": "matrix-core FLOPs executed per launch (padded tiles counted) / event-timed launch duration",
+            "executed_flops_per_launch": round(executed / len(dom), 1),
+            "avg_launch_ms": round(dom_ms / len(dom), 4),
+            "algorithmic": {"flops_per_launch": round(algorithmic / len(dom), 1), "tflops": round(alg, 2),
+                            "frac_of_direct_conv_roof": round(alg / peak, 4),
+                            "note": "direct-convolution FLOP count of SURVEY.md 8d; Winograd executes 1/2.25 of it"},
+            "algorithmic_bytes_per_launch": round(sum(launches[i]["act_bytes"] * b + launches[i]["weight_bytes"]
+                                                      for i in dom) / len(dom) * (0.5 if algo == "direct_f16" else 1.0))}
+
+
+def forward_summary(ms_mean, b, algo, peak):
+    from audiodenoiser_amd.roofline import PEAK_HBM_GBS, executed_mfma_flops, unet_launches
+    launches = unet_launches(F_BINS, T_FRAMES)
+    half = 0.5 if algo == "direct_f16" else 1.0
+    fwd_ms = float(ms_mean.sum())
+    tot_flops = sum(l["flops"] for l in launches) * b
+    tot_exec = sum(executed_mfma_flops(l, algo if l["kind"] == "conv3x3" else ("direct_f16" if half < 1 else "direct"))
+                   for l in launches) * b
+    tot_bytes = (sum(l["act_bytes"] for l in launches) * b + sum(l["weight_bytes"] for l in launches)) * half
+    return {"kernel_ms": round(fwd_ms, 3),
+            "algorithmic_tflops": round(tot_flops / (fwd_ms * 1e-3) / 1e12, 2),
+            "executed_mfma_tflops": round(tot_exec / (fwd_ms * 1e-3) / 1e12, 2),
+            "frac_mfma_peak_executed": round(tot_exec / (fwd_ms * 1e-3) / 1e12 / peak, 4),
+            "algorithmic_GBps": round(tot_bytes / (fwd_ms * 1e-3) / 1e9, 1),
+            "frac_hbm_peak": round(tot_bytes / (fwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+            "per_launch_ms": {l["name"]: round(float(m), 4) for l, m in zip(launches, ms_mean)}}
+
+
+def bench_stft(dev, clips=10000, length=132300, n_fft=1024, hop=256, steps=20, warmup=3, cpu_clips=64):
+    """BASELINE configs[2] on one GPU; inputs resident in HBM; events on the launch stream (torch's current stream)."""
+    from audiodenoiser_amd import _lib
+    from audiodenoiser_amd.stft import stft_n_frames
+    g = torch.Generator(device=dev).manual_seed(0)
+    a = torch.rand((clips, length), generator=g, device=dev) * 2 - 1
+    nfr = stft_n_frames(length, n_fft, hop, True)
+    nb = n_fft // 2 + 1
+    out = torch.empty((clips, nb, nfr), dtype=torch.float32, device=dev)
+    L = _lib.load()
+    st = torch.cuda.current_stream(dev).cuda_stream
+
+    def run():
+        _lib.check(L.adn_stft_mag(a.data_ptr(), clips, length, n_fft, hop, 1, out.data_ptr(), st), "adn_stft_mag")
+    for _ in range(warmup):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(dev)
+    e0.record()
+    for _ in range(steps):
+        run()
+    e1.record()
+    torch.cuda.synchronize(dev)
+    ms = e0.elapsed_time(e1) / steps
+    bytes_per_clip = length * 4 + nb * nfr * 4
+    gbs = clips * bytes_per_clip / (ms * 1e-3) / 1e9
+    traffic, source = tracked_traffic("stft_wave_kernel")
+    res = {"workload": f"BASELINE configs[2]: {clips} clips x {length} samples (3 s @ 44.1 kHz), n_fft {n_fft}, hop {hop}, "
+                       f"centred -> {clips} x {nb} x {nfr} fp32 magnitudes",
+           "steps": steps, "warmup": warmup, "ms_per_launch": round(ms, 4),
+           "clips_per_s": round(clips / (ms * 1e-3), 1), "frames_per_s": round(clips * nfr / (ms * 1e-3), 1),
+           "dtype": "f32",
+           "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
+                        "frac": round(gbs / 8000.0, 4), "traffic": traffic, "traffic_source": source,
+                        "kernel": "stft_wave_kernel<512,4,16>, 1 launch per step",
+                        "algorithmic_bytes_per_launch": clips * bytes_per_clip, "bytes_per_clip": bytes_per_clip}}
+    if cpu_clips > 0:
+        import oracle
+        host = a[:cpu_clips].cpu().numpy()
+        oracle.stft_mag(host[:2], n_fft, hop, True)
+        t0 = time.perf_counter()
+        oracle.stft_mag(host, n_fft, hop, True)
+        el = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": round(cpu_clips / el, 1), "unit": "clips/s", "cores": oracle.num_threads(),
+                               "kind": "port", "sample": f"{cpu_clips} of the same clips ({el:.2f} s), oracle/adn_oracle.c "
+                                                         "(float64 radix-2 FFT, OpenMP)"}
+    del a, out
+    torch.cuda.empty_cache()
+    return res
+
+
+def bench_f16(sd_np, dev, batch=256, steps=10, warmup=2):
+    """BASELINE configs[4] on one GPU: fp16 storage + fp16 MFMA forward at batch 256 (+ per-clip loss, as the main step)."""
+    from audiodenoiser_amd import _lib
+    from audiodenoiser_amd.loss import perceptual_loss_per_clip
+    from audiodenoiser_amd.roofline import PEAK_MFMA_F16_TFLOPS
+    net = make_net(sd_np, dev, "f16")
+    g = torch.Generator(device=dev).manual_seed(0)
+    x = torch.rand((batch, 1, F_BINS, T_FRAMES), generator=g, device=dev) * 4.0
+    target = torch.rand((batch, 1, F_BINS, T_FRAMES), generator=g, device=dev) * 4.0
+    L = _lib.load()
+    with torch.no_grad():
+        for _ in range(warmup):
+            loss = perceptual_loss_per_clip(net(x), target)
+        _lib.check(L.adn_unet_set_timing(net._handle, steps), "adn_unet_set_timing")
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = perceptual_loss_per_clip(net(x), target)
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+    assert bool(torch.isfinite(loss).all())
+    ms_mean = launch_timings(net, steps)
+    res = {"workload": f"BASELINE configs[4]: batch={batch} synthetic 513x256 spectrograms, full U-Net forward with fp16 "
+                       "storage + fp16 MFMA (fp32 accumulate) inside, fp32 at the boundary, + per-clip perceptual loss",
+           "steps": steps, "warmup": warmup, "dtype": "f16", "ms_per_step": round(el / steps * 1e3, 3),
+           "frames_per_s": round(batch * T_FRAMES * steps / el, 1),
+           "roofline": conv_roofline(ms_mean, batch, "direct_f16", PEAK_MFMA_F16_TFLOPS,
+                                     "conv_mfma<_Float16> (direct implicit GEMM, v_mfma_f32_32x32x16_f16)", "conv_mfma_f16"),
+           "forward": forward_summary(ms_mean, batch, "direct_f16", PEAK_MFMA_F16_TFLOPS)}
+    net._release()
+    del net, x, target
+    torch.cuda.empty_cache()
+    return res
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100, help="timed steps (default 100: >= 5 s of timed region)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch-per-gpu", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the stft (configs[2]) and f16 (configs[4]) sub-benchmarks")
+    ap.add_argument("--stft-steps", type=int, default=20)
+    ap.add_argument("--f16-steps", type=int, default=10)
+    ap.add_argument("--no-stft-cpu", action="store_true", help="skip the C-oracle STFT timing inside the stft sub-benchmark")
     ap.add_argument("--dtype", choices=("f32", "f16"), default="f32",
-                    help="f32 = headline metric (default); f16 = BASELINE configs[4] (fp16 storage + fp16 MFMA)")
+                    help="f32 = headline metric (default); f16 = run the MAIN loop on the fp16 path (BASELINE configs[4])")
     args = ap.parse_args()
 
     from audiodenoiser_amd import _lib
     from audiodenoiser_amd import distributed as D
     from audiodenoiser_amd.loss import perceptual_loss_per_clip
-    from audiodenoiser_amd.model import UNet
-    from audiodenoiser_amd.roofline import PEAK_HBM_GBS, PEAK_MFMA_F32_TFLOPS, unet_launches
+    from audiodenoiser_amd.roofline import PEAK_MFMA_F16_TFLOPS, PEAK_MFMA_F32_TFLOPS
     from audiodenoiser_amd.weights import make_state_dict
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device (no CPU path)")
+    if args.steps < 1 or args.steps > 4096:
+        raise SystemExit("--steps must be in [1, 4096]")
     rank, local_rank, world = D.init_from_env("nccl")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
@@ -122,9 +309,7 @@ def main() -> None:
     torch.cuda.set_device(dev)
 
     sd_np = make_state_dict(1234)                                     # replicated weights, regenerated per rank
-    net = UNet(1, 1)
-    net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd_np.items()}, strict=True)
-    net = net.to(dev).eval().set_compute_dtype(args.dtype)
+    net = make_net(sd_np, dev, args.dtype)
     f16 = args.dtype == "f16"
 
     b = args.batch_per_gpu
@@ -137,10 +322,10 @@ def main() -> None:
         loss = perceptual_loss_per_clip(y, target)            # (b, 4): total, stft, mel, l1 per clip
         return D.gather_per_clip(loss.reshape(-1))
 
+    L = _lib.load()
     with torch.no_grad():
         for _ in range(args.warmup):
             allv = step()
-        L = _lib.load()
         _lib.check(L.adn_unet_set_timing(net._handle, args.steps), "adn_unet_set_timing")
         D.barrier()
         torch.cuda.synchronize(dev)
@@ -152,33 +337,16 @@ def main() -> None:
         elapsed = time.perf_counter() - t0
     elapsed = D.max_over_ranks(elapsed, dev)
     assert allv.numel() == 4 * b * world and bool(torch.isfinite(allv).all())
-
-    # per-launch durations of the timed steps (events recorded on the launch stream inside libadn)
-    ms = np.zeros((args.steps, 23), dtype=np.float32)
-    for i in range(args.steps):
-        _lib.check(L.adn_unet_get_timing(net._handle, i, ms[i].ctypes.data_as(_lib.c_float_p)), "adn_unet_get_timing")
-    _lib.check(L.adn_unet_set_timing(net._handle, 0), "adn_unet_set_timing")
-    ms_mean = ms.mean(axis=0)
+    ms_mean = launch_timings(net, args.steps)      # per-launch durations of the timed steps (events inside libadn)
 
     if rank == 0:
-        launches = unet_launches(F_BINS, T_FRAMES)
-        peak = 2516.6 if f16 else PEAK_MFMA_F32_TFLOPS      # dense MFMA peak of the arithmetic type (MI355X_MICROARCH.md)
-        direct = f16 or os.environ.get("ADN_CONV_ALGO") == "direct"
-        dom = [i for i, l in enumerate(launches) if l["kind"] == "conv3x3"]
-        dom_flops = sum(launches[i]["flops"] for i in dom) * b          # per forward of this rank
-        dom_ms = float(ms_mean[dom].sum())
-        achieved = dom_flops / (dom_ms * 1e-3) / 1e12
-        tot_flops = sum(l["flops"] for l in launches) * b
-        tot_bytes = (sum(l["act_bytes"] for l in launches) * b + sum(l["weight_bytes"] for l in launches)) * (0.5 if f16 else 1.0)
-        fwd_ms = float(ms_mean.sum())
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                with open(tpath) as fh:
-                    traffic = json.load(fh).get("dominant_bytes_per_launch")
-            except (OSError, ValueError):
-                traffic = None
+        direct = f16 or not bool(net_uses_winograd())
+        algo = "direct_f16" if f16 else ("direct" if direct else "winograd")
+        peak = PEAK_MFMA_F16_TFLOPS if f16 else PEAK_MFMA_F32_TFLOPS
+        kname = ("conv_mfma<_Float16> (direct implicit GEMM, fp16 MFMA)" if f16 else
+                 "conv_mfma<float> (direct implicit GEMM, fp32 MFMA)" if direct else
+                 "wino_conv_dma_f32 (Winograd F(2x2,3x3), fp32 MFMA v_mfma_f32_16x16x4_f32)")
+        tkey = "conv_mfma_f16" if f16 else ("conv_mfma_f32" if direct else "wino_conv_dma_f32")
         frames = b * world * T_FRAMES * args.steps
         out = {
             "metric": "spectrogram frames/sec (forward), 513x256 fp32",
@@ -195,31 +363,31 @@ def main() -> None:
             "data": "synthetic",
             "config": {"workload": f"batch={b} per GPU synthetic 513x256 fp32 spectrograms, full U-Net forward "
                                    + ("[fp16 storage + fp16 MFMA inside, BASELINE configs[4]] " if f16 else "")
-                                   +
-                                   "(BASELINE configs[1]) + per-clip perceptual loss" + (" + all-gather" if world > 1 else ""),
+                                   + "(BASELINE configs[1]) + per-clip perceptual loss" + (" + all-gather" if world > 1 else ""),
                        "batch_per_gpu": b, "global_batch": b * world, "freq_bins": F_BINS, "frames": T_FRAMES,
-                       "parallelism": f"clips sharded over {world} rank(s), weights replicated"},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
-                         "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None if direct else traffic,
-                         "kernel": (("conv_mfma<f16> (direct implicit GEMM, fp16 MFMA)" if f16 else
-                                     "conv_mfma<f32> (direct implicit GEMM)") if direct
-                                    else "wino_conv_dma_f32 (Winograd F(2x2,3x3), fp32 MFMA)") + ", 17 launches per forward",
-                         "mfma_util": round(achieved / peak / (1.0 if direct else 2.25), 4),
-                         "flops_per_launch": round(dom_flops / len(dom), 1),
-                         "avg_launch_ms": round(dom_ms / len(dom), 4)},
-            "forward": {"kernel_ms": round(fwd_ms, 3),
-                        "tflops": round(tot_flops / (fwd_ms * 1e-3) / 1e12, 2),
-                        "frac_mfma_peak": round(tot_flops / (fwd_ms * 1e-3) / 1e12 / peak, 4),
-                        "algorithmic_GBps": round(tot_bytes / (fwd_ms * 1e-3) / 1e9, 1),
-                        "frac_hbm_peak": round(tot_bytes / (fwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-                        "per_launch_ms": {l["name"]: round(float(m), 4) for l, m in zip(launches, ms_mean)}},
+                       "parallelism": f"clips sharded over {world} rank(s), weights replicated",
+                       "timed_region_s": round(elapsed, 3), "lib_digest": lib_digest()[:12]},
+            "roofline": conv_roofline(ms_mean, b, algo, peak, kname, tkey),
+            "forward": forward_summary(ms_mean, b, algo, peak),
         }
+        del allv
+        if world == 1 and not args.no_extras:
+            net._workspace = None
+            torch.cuda.empty_cache()
+            out["stft"] = bench_stft(dev, steps=args.stft_steps, cpu_clips=0 if args.no_stft_cpu else 64)
+            if not f16:
+                out["f16"] = bench_f16(sd_np, dev, steps=args.f16_steps)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(sd_np)
         print(json.dumps(out), flush=True)
     D.barrier()
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def net_uses_winograd() -> bool:
+    """The fp32 3x3 layers run the Winograd kernel unless ADN_CONV_ALGO=direct was set when the handle was created."""
+    return os.environ.get("ADN_CONV_ALGO") != "direct"
 
 
 if __name__ == "__main__":

@@ -97,6 +97,92 @@ def test_unet_full_size_batch64(net, dev, weights_np):
         assert _rel(y[i:i + 1].cpu().numpy(), ref) <= TOL
 
 
+def test_unet_full_size_batch256_fp32(net, dev, weights_np):
+    """north_star's batch and the per-rank shard of BASELINE configs[3] (2048 clips over 8 GPUs = 256 per GPU),
+    fp32, 513x256: finite, clip independence bit-exact for three clips, two clips against the torch oracle."""
+    from oracle import unet_torch
+    n, f, t = 256, 513, 256
+    g = torch.Generator(device=dev).manual_seed(0)                 # bench.py's rank-0 shard generator
+    x = torch.rand((n, 1, f, t), generator=g, device=dev) * 4.0
+    with torch.no_grad():
+        y = net(x)
+        assert y.shape == x.shape and torch.isfinite(y).all()
+        for i in (0, 129, 255):
+            assert torch.equal(net(x[i:i + 1].clone())[0], y[i]), i
+    sd = unet_torch.to_torch_state(weights_np)
+    for i in (1, 254):
+        ref = unet_torch.unet_forward(sd, x[i:i + 1].cpu()).numpy()
+        assert _rel(y[i:i + 1].cpu().numpy(), ref) <= TOL
+    net._workspace = None                                          # 37 GB: give it back before the next test
+    torch.cuda.empty_cache()
+
+
+def test_reference_test_py_call_shape_cpu_model_cpu_tensors(dev, weights_np, golden_dir, tmp_path, monkeypatch):
+    """Literally the reference's inference caller (test.py:63-66,100,112-114,118-122) with PYTHONPATH=compat: the
+    model is loaded with map_location='cpu' and never moved, the batch is a CPU tensor, the loss inputs are CPU
+    tensors.  The mirror stages them on the current ROCm device, runs the HIP path and answers on the CPU."""
+    import importlib
+    import sys
+    from oracle import loss_torch
+    from audiodenoiser_amd.weights import make_input
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.syspath_prepend(os.path.join(root, "compat"))
+    for name in ("model", "loss"):
+        sys.modules.pop(name, None)
+    UNet = importlib.import_module("model").UNet                               # test.py:8  from model import UNet
+    CombinedPerceptualLoss = importlib.import_module("loss").CombinedPerceptualLoss   # test.py:9
+    model_path = str(tmp_path / "unet_denoiser_white.pth")
+    torch.save({k: torch.from_numpy(np.array(v)) for k, v in weights_np.items()}, model_path)
+    noisy_spectrograms = np.concatenate([make_input(7, 1, 257, 188)[:, 0]] +
+                                        [make_input(40 + i, 1, 257, 188)[:, 0] for i in range(4)])   # (5, 257, 188)
+    clean_spectrograms = np.concatenate([make_input(50 + i, 1, 257, 188)[:, 0] for i in range(5)])
+
+    model = UNet(in_channels=1, num_classes=1)                                                         # test.py:63
+    model.load_state_dict(torch.load(model_path, map_location='cpu', weights_only=True))               # test.py:65
+    model.eval()                                                                                       # test.py:66
+    noisy_torch = torch.tensor(noisy_spectrograms, dtype=torch.float32).unsqueeze(1)                   # test.py:100
+    with torch.no_grad():                                                                              # test.py:112
+        denoised_torch = model(noisy_torch)                                                            # test.py:113
+        denoised_spectrograms = denoised_torch.squeeze(1).cpu().numpy()                                # test.py:114
+    criterion = CombinedPerceptualLoss()                                                               # test.py:117
+    with torch.no_grad():
+        denoised_torch = torch.tensor(denoised_spectrograms, dtype=torch.float32).unsqueeze(1)
+        clean_torch = torch.tensor(clean_spectrograms, dtype=torch.float32).unsqueeze(1)
+        total_loss, stft_loss, mel_loss, l1_loss = criterion(denoised_torch, clean_torch)              # test.py:122
+
+    assert not noisy_torch.is_cuda and not any(p.is_cuda for p in model.parameters())                  # nothing was moved
+    g = np.load(os.path.join(golden_dir, "unet_257x188.npz"))
+    assert denoised_spectrograms.shape == (5, 257, 188)
+    assert _rel(denoised_spectrograms[0], g["y"][0, 0]) <= TOL                     # the reference's own forward
+    with torch.no_grad():                                                           # same clips as device tensors
+        on_dev = model(noisy_torch.to(dev))
+    assert on_dev.is_cuda and np.array_equal(on_dev.cpu().numpy()[:, 0], denoised_spectrograms)
+    ref = loss_torch.per_clip(denoised_torch, clean_torch).numpy().mean(axis=0)
+    got = np.array([total_loss.item(), stft_loss.item(), mel_loss.item(), l1_loss.item()])
+    assert not total_loss.is_cuda and np.allclose(got, ref, rtol=2e-4)
+    for name in ("model", "loss"):
+        sys.modules.pop(name, None)
+
+
+def test_c_abi_rejects_misaligned_buffers_and_keeps_the_current_device(net, dev):
+    from audiodenoiser_amd import _lib
+    L = _lib.load()
+    x = torch.zeros(1, 1, 16, 16, device=dev)
+    with torch.no_grad():
+        net(x)
+    need = ctypes.c_size_t()
+    _lib.check(L.adn_unet_workspace_bytes(net._handle, 1, 16, 16, ctypes.byref(need)), "ws")
+    ws = torch.empty(need.value + 64, dtype=torch.uint8, device=dev)
+    y = torch.empty_like(x)
+    before = torch.cuda.current_device()
+    assert L.adn_unet_forward(net._handle, x.data_ptr(), y.data_ptr(), 1, 16, 16, ws.data_ptr() + 4, need.value, None) == 1
+    assert b"aligned" in L.adn_last_error()
+    assert L.adn_unet_forward(net._handle, x.data_ptr() + 2, y.data_ptr(), 1, 16, 16, ws.data_ptr(), need.value, None) == 1
+    assert L.adn_unet_forward(net._handle, x.data_ptr(), y.data_ptr(), 1, 16, 16, ws.data_ptr() + 16, need.value, None) == 0
+    torch.cuda.synchronize()
+    assert torch.cuda.current_device() == before
+
+
 @pytest.mark.parametrize("algo", ["direct", "winograd"])
 def test_unet_both_conv_algorithms(dev, weights_np, golden_dir, algo, monkeypatch):
     """The 3x3 layers have two kernels: Winograd F(2x2,3x3) (default) and the direct implicit GEMM
@@ -178,6 +264,57 @@ def test_config0_wav_to_spectrogram_to_forward(net, dev, weights_np):
     assert y.shape == (1, 1, 513, 256) and _rel(y.cpu().numpy(), ref) <= TOL
 
 
+def test_config0_real_audio_stage_by_stage(net, dev, weights_np, golden_dir):
+    """BASELINE configs[0] on REAL audio: the bundled 3 s clip (tests/golden/real_audio_*.npz, frozen from
+    /root/reference/data/test/noise/17480-2-0-24.wav) -> STFT 1024/256 centred -> loader rule -> forward.  Each stage
+    against the oracle on the input the next stage consumes, and the loader + forward stages against
+    config0_real_audio.npz, which the reference's data_loader.py + model.py produced (tools/make_golden.py)."""
+    import oracle
+    from audiodenoiser_amd.data_loader import quantize_pad_on_device
+    from audiodenoiser_amd.stft import stft_magnitude
+    fx = np.load(os.path.join(golden_dir, "real_audio_17480-2-0-24.npz"))
+    g = np.load(os.path.join(golden_dir, "config0_real_audio.npz"))
+    clip = fx["lr_sum_int16"].astype(np.float32) / np.float32(65536.0)
+    mag = stft_magnitude(torch.from_numpy(clip).to(dev), 1024, 256, True)
+    assert tuple(mag.shape) == (513, 517)
+    assert _rel(mag.cpu().numpy(), oracle.stft_mag(clip, 1024, 256, True)) <= TOL
+    x = quantize_pad_on_device(mag[None], (513, 256))
+    xh = x.cpu().numpy()[0, 0]
+    assert np.array_equal(xh, oracle.quantize_pad(mag.cpu().numpy(), (513, 256)))        # bit exact on the same input
+    gx = g["x_f16"].astype(np.float32)
+    # device STFT vs oracle STFT differ by ~1e-7 relative, so a few values land on the other side of an fp16 rounding
+    # boundary: at most one fp16 ulp (2^-10 relative), and rarely
+    diff = xh != gx
+    assert diff.mean() < 2e-3 and np.all(np.abs(xh - gx)[diff] <= 2.0 ** -10 * np.abs(gx)[diff] + 6e-8)
+    with torch.no_grad():
+        y = net(torch.from_numpy(gx[None, None]).to(dev))                                 # the golden's own input
+        y_chain = net(x)                                                                  # the device chain's input
+    assert _rel(y.cpu().numpy()[0, 0], g["y"]) <= TOL
+    assert _rel(y_chain.cpu().numpy()[0, 0], g["y"]) <= 2e-3          # fp16-ulp input flips propagate, bounded
+
+
+def test_stft_silence_dc_and_gaps(dev, golden_dir):
+    """Signals the synthetic noise tests never produce: digital silence (exact zeros out), a DC offset, and the real
+    clip with a silent lead-in (frames inside the gap are exactly zero)."""
+    import oracle
+    from audiodenoiser_amd.stft import stft_magnitude
+    fx = np.load(os.path.join(golden_dir, "real_audio_17480-2-0-24.npz"))
+    clip = fx["lr_sum_int16"].astype(np.float32) / np.float32(65536.0)
+    gapped = clip.copy()
+    gapped[:30000] = 0.0
+    batch = np.stack([np.zeros_like(clip), gapped, clip + np.float32(0.25), clip])
+    m = stft_magnitude(torch.from_numpy(batch).to(dev), 1024, 256, True).cpu().numpy()
+    assert not m[0].any() and not m[1][:, :100].any()
+    for i in (1, 2, 3):
+        assert _rel(m[i], oracle.stft_mag(batch[i], 1024, 256, True)) <= TOL
+    dc = stft_magnitude(torch.full((8192,), 0.5, device=dev), 1024, 256, True).cpu().numpy()
+    assert np.allclose(dc[0, 4:-4], 256.0, rtol=1e-5) and np.allclose(dc[1, 4:-4], 128.0, rtol=1e-5)
+    assert dc[2:, 4:-4].max() < 1e-3
+    for n_fft, hop in ((512, 128), (256, 64)):                       # the reference's own setting and a smaller one
+        r = stft_magnitude(torch.from_numpy(clip[:24000]).to(dev), n_fft, hop, True).cpu().numpy()
+        assert _rel(r, oracle.stft_mag(clip[:24000], n_fft, hop, True)) <= TOL
+
+
 # ---------------------------------------------------------------------------------------------- STFT
 STFT_CASES = [(16000, 512, 128, False), (24000, 512, 128, True), (132300, 1024, 256, True),
               (132300, 1024, 256, False), (5000, 2048, 512, True), (4096, 4096, 1024, False),
@@ -242,6 +379,28 @@ def test_stft_full_size_properties(dev):
     for i in (0, 777, n_clips - 1):
         assert torch.equal(stft_magnitude(a[i], 1024, 256, True), m[i])
         assert _rel(m[i].cpu().numpy(), oracle.stft_mag(a[i].cpu().numpy(), 1024, 256, True)) <= TOL
+
+
+def test_stft_config2_full_size_10000_clips(dev):
+    """BASELINE configs[2] at its stated size: 10 000 clips x 132 300 samples (5.3 GB in, 10.6 GB out), n_fft 1024,
+    hop 256, centred: exact homogeneity, clip independence, three clips against the oracle."""
+    import oracle
+    from audiodenoiser_amd.stft import stft_magnitude
+    n_clips, L = 10000, 132300
+    g = torch.Generator(device=dev).manual_seed(0)
+    a = torch.rand((n_clips, L), generator=g, device=dev) * 2 - 1
+    m = stft_magnitude(a, 1024, 256, True)
+    assert m.shape == (n_clips, 513, 517)
+    assert bool(torch.isfinite(m).all())
+    m2 = stft_magnitude(a * 2.0, 1024, 256, True)
+    m2 *= 0.5                                                        # scaling by a power of two is exact
+    assert torch.equal(m2, m)
+    del m2
+    for i in (0, 4999, n_clips - 1):
+        assert torch.equal(stft_magnitude(a[i], 1024, 256, True), m[i])
+        assert _rel(m[i].cpu().numpy(), oracle.stft_mag(a[i].cpu().numpy(), 1024, 256, True)) <= TOL
+    del m, a
+    torch.cuda.empty_cache()
 
 
 def test_stft_rejects_bad_arguments(dev):
@@ -311,6 +470,23 @@ def test_perceptual_loss_per_clip(dev, b, f, t):
     total, stft, mel, l1 = CombinedPerceptualLoss()(pred.to(dev), tgt.to(dev))
     assert abs(float(l1) - float(torch.nn.functional.l1_loss(pred, tgt))) < 1e-5
     assert abs(float(total) - float(ref[:, 0].mean())) < 1e-4 * float(ref[:, 0].mean())
+
+
+@pytest.mark.parametrize("t", [2688, 2704, 4094, 6784])
+def test_perceptual_loss_long_clips(dev, t):
+    """Frame counts beyond 64 KiB of LDS per clip (T >= 2689) up to the documented limit ADN_LOSS_MAX_FRAMES."""
+    from oracle import loss_torch
+    from audiodenoiser_amd.loss import perceptual_loss_per_clip
+    g = torch.Generator().manual_seed(t)
+    pred = torch.rand((2, 1, 24, t), generator=g) * 3
+    tgt = torch.rand((2, 1, 24, t), generator=g) * 3
+    ref = loss_torch.per_clip(pred, tgt).numpy()
+    got = perceptual_loss_per_clip(pred.to(dev), tgt.to(dev)).cpu().numpy()
+    assert np.allclose(got, ref, rtol=2e-4, atol=1e-6)
+    from audiodenoiser_amd._lib import AdnError
+    if t == 6784:
+        with pytest.raises(AdnError, match="6784"):
+            perceptual_loss_per_clip(torch.zeros((1, 1, 8, t + 1), device=dev), torch.zeros((1, 1, 8, t + 1), device=dev))
 
 
 def test_perceptual_loss_zero_and_errors(dev):
@@ -395,6 +571,14 @@ def test_wav_to_spec_dataset_matches_oracle(dev, tmp_path):
     assert torch.equal(nb[0].cpu(), ds[0][0]) and torch.equal(cb[1].cpu(), ds[1][1])
     with pytest.raises(ValueError):
         WavToSpecDataset(str(tmp_path), sample_rate=16000, device=dev)[0]
+    # the DataLoader feed of train.py:118-119: workers decode audio only (host), the main process collates on the device
+    from torch.utils.data import DataLoader
+    loader = DataLoader(ds.audio_view(8000), batch_size=2, num_workers=2, collate_fn=ds.collate_to_device)
+    batches = list(loader)
+    assert len(batches) == 2 and all(b[0].is_cuda and b[0].shape == (2, 1, 256, 64) for b in batches)
+    assert torch.equal(batches[0][0], nb) and torch.equal(batches[0][1], cb)         # items 0, 1 are 8000 samples long
+    with pytest.raises(RuntimeError, match="DataLoader worker"):
+        next(iter(DataLoader(ds, batch_size=2, num_workers=1)))
 
 
 @pytest.mark.gpu

@@ -354,3 +354,24 @@ def test_forward_shape_limits_are_reported():
     assert L.adn_unet_workspace_bytes(None, 1, 64, 4096, ctypes.byref(need)) == 1
     assert b"T<=4094" in L.adn_last_error()
     assert L.adn_unet_workspace_bytes(None, 1, 8192, 4000, ctypes.byref(need)) == 1
+
+
+def test_roofline_accounting():
+    """bench.py's roofline inputs: SURVEY 8d totals, and executed matrix-core FLOPs (padded tiles counted)."""
+    from audiodenoiser_amd.roofline import executed_mfma_flops, totals, unet_launches
+    flops, act, wts = totals(513, 256)
+    assert abs(flops / 1e9 - 192.443) < 1e-3 and abs(act / 1e6 - 670.63) < 0.1 and abs(wts / 1e6 - 124.12) < 0.05
+    ls = unet_launches(513, 256)
+    c3 = [l for l in ls if l["kind"] == "conv3x3"]
+    assert len(c3) == 17
+    for l in c3:
+        w, d = executed_mfma_flops(l, "winograd"), executed_mfma_flops(l, "direct")
+        assert w <= l["flops"] / 2.25 * 1.03 and w >= l["flops"] / 2.25          # only 513 -> 528 row padding on top
+        assert l["flops"] <= d <= l["flops"] * 1.03
+    assert executed_mfma_flops(ls[0], "winograd") == 0.0 and executed_mfma_flops(ls[-1], "direct") == 0.0
+    even = unet_launches(512, 256)
+    for l in even:
+        if l["kind"] == "conv3x3":
+            assert executed_mfma_flops(l, "winograd") * 2.25 == l["flops"]
+        if l["kind"] == "convt":
+            assert executed_mfma_flops(l, "direct") == l["flops"]

@@ -2,12 +2,16 @@
 """Summarise rocprofv3 outputs into profiles/: per-kernel stats, and HBM traffic from separate PMC passes.
 
     python tools/pmc_summary.py --stats gpurun_out/prof/stats --fetch gpurun_out/prof/fetch \
-        --write gpurun_out/prof/write --tag r01
+        --write gpurun_out/prof/write --tag r02_bench --cmd "python3 bench.py --steps 5 ..." [--traffic-json]
 
 HBM bytes per dispatch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE / WRITE_SIZE are in KiB and on gfx950
 FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming read, so it is doubled
-(/opt/skills/guides/MI355X_MICROARCH.md §HBM, cdna_hip_programming.md §7).  FETCH and WRITE come from two
-separate rocprofv3 --pmc runs of the same command (they do not fit one pass).
+(/opt/skills/guides/MI355X_MICROARCH.md, HBM).  FETCH and WRITE come from two separate rocprofv3 --pmc runs of the
+same command (they do not fit one pass).
+
+With --traffic-json the per-family means are written to profiles/pmc_traffic.json together with the source digest of
+the libadn.so that was profiled (audiodenoiser_amd/_lib/libadn.sha256); bench.py reports `roofline.traffic` only
+when that digest equals the library it is running.
 """
 import argparse
 import csv
@@ -16,6 +20,20 @@ import json
 import os
 import re
 from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# kernel families bench.py asks for (key -> predicate on the short kernel name)
+FAMILIES = {
+    "wino_conv_dma_f32": lambda n: n.startswith("wino_conv_dma_f32"),
+    "conv_mfma_f32": lambda n: n.startswith("conv_mfma<float") and ", 9, " in n,
+    "conv_mfma_f16": lambda n: n.startswith("conv_mfma<_Float16") and ", 9, " in n,
+    "convt_f32": lambda n: n.startswith("conv_mfma<float") and ", 1, 4, 2>" in n,
+    "convt_f16": lambda n: n.startswith("conv_mfma<_Float16") and ", 1, 4, 2>" in n,
+    "stft_wave_kernel": lambda n: n.startswith("stft_wave_kernel"),
+    "conv_first_kernel": lambda n: n.startswith("conv_first_kernel"),
+    "conv_out_kernel": lambda n: n.startswith("conv_out_kernel"),
+}
 
 
 def short(name: str) -> str:
@@ -43,17 +61,13 @@ def main():
     ap.add_argument("--stats")
     ap.add_argument("--fetch")
     ap.add_argument("--write")
-    ap.add_argument("--tag", default="r01")
-    ap.add_argument("--out", default="profiles")
-    ap.add_argument("--cmd", default="python bench.py --steps 5 --warmup 2 --no-cpu-baseline")
-    ap.add_argument("--dominant", default="wino_conv_dma_f32", help="kernel-name prefix of the dominant kernel")
-    ap.add_argument("--dominant-filter", default="", help="substring selecting its instantiations")
+    ap.add_argument("--tag", default="r02")
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles"))
+    ap.add_argument("--cmd", default="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline")
+    ap.add_argument("--traffic-json", action="store_true", help="(re)write profiles/pmc_traffic.json")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     lines = []
-
-    def dominant(n):
-        return n.startswith(args.dominant) and args.dominant_filter in n
 
     if args.stats:
         for path in glob.glob(os.path.join(args.stats, "**", "*_kernel_stats.csv"), recursive=True):
@@ -61,27 +75,28 @@ def main():
                 rows = list(csv.DictReader(fh))
             lines.append(f"# rocprofv3 --kernel-trace --stats -- {args.cmd}")
             lines.append(f"{'kernel':92s} {'calls':>6s} {'total_ms':>10s} {'avg_ms':>9s} {'pct':>6s}")
-            tot = [0, 0.0]
+            fam = defaultdict(lambda: [0, 0.0])
             for r in rows:
                 n = short(r["Name"])
                 if not ours(n):
                     continue
                 lines.append(f"{n:92s} {int(r['Calls']):6d} {float(r['TotalDurationNs']) / 1e6:10.3f} "
                              f"{float(r['AverageNs']) / 1e6:9.4f} {float(r['Percentage']):6.2f}")
-                if dominant(n):
-                    tot[0] += int(r["Calls"])
-                    tot[1] += float(r["TotalDurationNs"]) / 1e6
-            if tot[0]:
-                lines.append(f"dominant kernel {args.dominant} (all selected instantiations): {tot[0]} launches, "
-                             f"{tot[1]:.3f} ms total, {tot[1] / tot[0]:.4f} ms average per launch")
+                for key, pred in FAMILIES.items():
+                    if pred(n):
+                        fam[key][0] += int(r["Calls"])
+                        fam[key][1] += float(r["TotalDurationNs"]) / 1e6
+            for key, (calls, tot) in fam.items():
+                lines.append(f"family {key}: {calls} launches, {tot:.3f} ms total, {tot / calls:.4f} ms average per launch")
     traffic = {}
     if args.fetch and args.write:
         fetch = read_counter(args.fetch, "FETCH_SIZE")
         write = read_counter(args.write, "WRITE_SIZE")
         lines.append("")
-        lines.append("# HBM traffic per dispatch from two separate --pmc passes: (2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes")
+        lines.append(f"# HBM traffic per dispatch from two separate --pmc passes of `{args.cmd}`: "
+                     "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes")
         lines.append(f"{'kernel':92s} {'disp':>5s} {'fetch_MiB(x2)':>14s} {'write_MiB':>10s} {'total_MiB':>10s}")
-        agg = [0, 0.0]
+        agg = defaultdict(lambda: [0, 0.0])
         for n in sorted(fetch):
             if not ours(n):
                 continue
@@ -90,21 +105,29 @@ def main():
             fb = 2 * sum(f) / len(f) * 1024
             wb = sum(w) / len(w) * 1024
             lines.append(f"{n:92s} {len(f):5d} {fb / 2**20:14.2f} {wb / 2**20:10.2f} {(fb + wb) / 2**20:10.2f}")
-            if dominant(n):
-                agg[0] += len(f)
-                agg[1] += (fb + wb) * len(f)
-        if agg[0]:
-            traffic["dominant_bytes_per_launch"] = round(agg[1] / agg[0])
-            traffic["dominant_kernel"] = args.dominant
-            traffic["note"] = ("mean over the dominant kernel's dispatches of bench.py (batch 64): (2*FETCH_SIZE + "
-                               "WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes; the x2 is the gfx950 FETCH_SIZE "
-                               "correction of MI355X_MICROARCH.md")
-            lines.append(f"{args.dominant} mean HBM bytes per launch: {traffic['dominant_bytes_per_launch']}")
+            for key, pred in FAMILIES.items():
+                if pred(n):
+                    agg[key][0] += len(f)
+                    agg[key][1] += (fb + wb) * len(f)
+        for key, (cnt, tot) in agg.items():
+            traffic[key] = {"bytes_per_launch": round(tot / cnt), "dispatches": cnt, "cmd": args.cmd}
+            lines.append(f"family {key}: mean HBM bytes per launch {round(tot / cnt)} over {cnt} dispatches")
     with open(os.path.join(args.out, f"{args.tag}_rocprof_summary.txt"), "w") as fh:
         fh.write("\n".join(lines) + "\n")
-    if traffic:
+    if traffic and args.traffic_json:
+        digest = ""
+        try:
+            with open(os.path.join(ROOT, "audiodenoiser_amd", "_lib", "libadn.sha256")) as fh:
+                digest = fh.read().strip()
+        except OSError:
+            pass
+        rec = {"lib_digest": digest,
+               "note": "mean over each kernel family's dispatches: (2*FETCH_SIZE + WRITE_SIZE)*1024 from two separate "
+                       "rocprofv3 --pmc passes; the x2 is the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md; "
+                       "lib_digest = source digest of the libadn.so that was profiled",
+               "kernels": traffic}
         with open(os.path.join(args.out, "pmc_traffic.json"), "w") as fh:
-            json.dump(traffic, fh, indent=1)
+            json.dump(rec, fh, indent=1)
     print("\n".join(lines))
 
 
