@@ -104,9 +104,10 @@ class WavToSpecDataset(Dataset):
     * ``ds[i]`` (main process, ``num_workers=0``): device STFT, items come back as host tensors like the reference's
       datasets.  Inside a DataLoader WORKER process it raises: workers are forked from a parent that has already
       initialised HIP (``model.to(DEVICE)``, ``train.py:122``) and a forked child cannot use the GPU.
-    * ``DataLoader(ds.audio_view(clip_samples), num_workers=4, collate_fn=ds.collate_to_device)``: the workers only
-      decode wav files (host I/O) and hand back fixed-length audio; the main process runs ONE batched device STFT per
-      batch and yields ``(noisy, clean)`` batches ``(B, 1, H, W)`` already resident in HBM -- the MI355X-shaped feed.
+    * ``ds.loader(clip_samples, batch_size=16, num_workers=4, pin_memory=True, shuffle=True)``: a ``DataLoader`` over
+      :meth:`audio_view` whose workers only decode wav files (host I/O) and collate fixed-length audio; the MAIN
+      process then runs ONE batched device STFT per batch and yields ``(noisy, clean)`` batches ``(B, 1, H, W)``
+      already resident in HBM -- the MI355X-shaped feed (a ``collate_fn`` cannot do this: it runs in the worker).
     * ``load_batch_to_device(indices)``: the same without a DataLoader.
 
     No resampling: ``sample_rate`` (if given) is checked against each file.
@@ -148,7 +149,7 @@ class WavToSpecDataset(Dataset):
             raise RuntimeError(
                 "WavToSpecDataset computes its spectrograms on the GPU (there is no host STFT) and a DataLoader worker "
                 "process forked from a GPU-initialised parent cannot use HIP.  Use num_workers=0, or let the workers "
-                "decode audio only: DataLoader(ds.audio_view(clip_samples), num_workers=4, collate_fn=ds.collate_to_device)")
+                "decode audio only and transform in the main process: ds.loader(clip_samples, batch_size=..., num_workers=4)")
         noisy_path, clean_path = self.pairs[idx]
         noisy, clean = self._audio(noisy_path), self._audio(clean_path)
         if len(noisy) == len(clean):
@@ -162,18 +163,38 @@ class WavToSpecDataset(Dataset):
         clean = [self._audio(self.pairs[i][1]) for i in indices]
         return self._spec_batch(noisy), self._spec_batch(clean)
 
-    # ---- DataLoader feed: host-only items, device collate ------------------------------------------------
+    # ---- DataLoader feed: host-only items in the workers, device transform in the main process ---------------
     def audio_view(self, clip_samples: int):
         """Host-only ``Dataset`` of ``(noisy_audio, clean_audio)`` float32 tensors cropped / zero-padded at the end to
         ``clip_samples`` -- safe in DataLoader worker processes (wav decoding only, no GPU)."""
         return _WavAudioView(self, int(clip_samples))
 
-    def collate_to_device(self, batch):
-        """``collate_fn`` for :meth:`audio_view`: runs in the DataLoader's main process; one batched device STFT +
-        quantise + crop/pad per side -> ``(noisy, clean)`` each ``(B, 1, H, W)`` float32 on the device."""
-        noisy = torch.stack([b[0] for b in batch])
-        clean = torch.stack([b[1] for b in batch])
+    def to_device_batch(self, host_batch):
+        """``(noisy_audio (B, L), clean_audio (B, L))`` host tensors (what a DataLoader over :meth:`audio_view` yields)
+        -> ``(noisy, clean)`` each ``(B, 1, H, W)`` float32 on the device: one batched STFT + quantise + crop/pad per
+        side.  Must run in the process that owns the GPU context (the DataLoader's consumer, not its workers)."""
+        noisy, clean = host_batch
         return self._spec_batch(noisy), self._spec_batch(clean)
+
+    def loader(self, clip_samples: int, **dataloader_kwargs):
+        """Iterable with the ``DataLoader`` call shape of ``train.py:118-119`` (``batch_size``, ``shuffle``,
+        ``num_workers``, ``pin_memory``, ...) that yields device-resident spectrogram batches."""
+        from torch.utils.data import DataLoader
+        if "collate_fn" in dataloader_kwargs:
+            raise ValueError("loader(): the collate function is fixed (stacked fixed-length audio)")
+        return _DeviceSpecLoader(self, DataLoader(self.audio_view(clip_samples), **dataloader_kwargs))
+
+
+class _DeviceSpecLoader:
+    def __init__(self, parent: "WavToSpecDataset", host_loader):
+        self.parent, self.host_loader = parent, host_loader
+
+    def __len__(self):
+        return len(self.host_loader)
+
+    def __iter__(self):
+        for host_batch in self.host_loader:
+            yield self.parent.to_device_batch(host_batch)
 
 
 class _WavAudioView(Dataset):

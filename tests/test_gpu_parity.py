@@ -571,9 +571,10 @@ def test_wav_to_spec_dataset_matches_oracle(dev, tmp_path):
     assert torch.equal(nb[0].cpu(), ds[0][0]) and torch.equal(cb[1].cpu(), ds[1][1])
     with pytest.raises(ValueError):
         WavToSpecDataset(str(tmp_path), sample_rate=16000, device=dev)[0]
-    # the DataLoader feed of train.py:118-119: workers decode audio only (host), the main process collates on the device
+    # the DataLoader feed of train.py:118-119: workers decode audio only (host), the main process transforms on the device
     from torch.utils.data import DataLoader
-    loader = DataLoader(ds.audio_view(8000), batch_size=2, num_workers=2, collate_fn=ds.collate_to_device)
+    loader = ds.loader(8000, batch_size=2, num_workers=2, pin_memory=True)
+    assert len(loader) == 2
     batches = list(loader)
     assert len(batches) == 2 and all(b[0].is_cuda and b[0].shape == (2, 1, 256, 64) for b in batches)
     assert torch.equal(batches[0][0], nb) and torch.equal(batches[0][1], cb)         # items 0, 1 are 8000 samples long

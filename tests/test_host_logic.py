@@ -250,7 +250,7 @@ def test_wav_dataset_discovery_and_subset(tmp_path, capsys):
 def test_wav_dataset_worker_guard_and_audio_view(tmp_path):
     """train.py:118-119 wraps the dataset in DataLoader(num_workers=4): __getitem__ needs the GPU, so inside a worker
     it must fail with a clear message (not hang on a forked HIP context); the audio view is host-only and works in
-    workers, its collate runs the device STFT in the main process."""
+    workers; ds.loader() runs the device STFT on their batches in the main process."""
     from torch.utils.data import DataLoader
     from audiodenoiser_amd.data_loader import WavToSpecDataset
     from audiodenoiser_amd.wav import write_wav
@@ -274,6 +274,9 @@ def test_wav_dataset_worker_guard_and_audio_view(tmp_path):
     assert np.array_equal(n1.numpy(), read_wav(str(tmp_path / "noisy_1.wav"))[0][:1000])
     with pytest.raises(ValueError):
         ds.audio_view(100)
+    with pytest.raises(ValueError):
+        ds.loader(1000, collate_fn=lambda b: b)
+    assert len(ds.loader(1000, batch_size=3, num_workers=2)) == 2
 
 
 def test_cpu_tensors_without_a_device_raise_instead_of_computing(weights_np):
