@@ -317,6 +317,37 @@ __global__ __launch_bounds__(NW * 64, WPE) void stft_wave_kernel(const float *__
     float *oclip = out + (long)clip * (M + 1) * n_frames;
     v2f *sc = s_sc + slot * SCSZ;
 
+    const int Li = (int)L;                                // adn_stft_mag guarantees L < 2^30
+    const bool base_aligned = (reinterpret_cast<uintptr_t>(aud) & 7) == 0;
+
+    // raw (unwindowed) samples of frame `fidx` of this clip -> dst[8]
+    auto load_frame = [&](int fidx, v2f *dst) {
+        const int fstart = fidx * hop - pad;               // may be < 0 (centre padding) or run past the clip
+        const float *ap = aud + fstart + 2 * t;
+        if (ablate & 1) {                                  // timing experiment only: no audio traffic
+#pragma unroll
+            for (int u = 0; u < 8; ++u) dst[u] = v2f{(float)(fidx + u), 1.f};
+        } else if (fstart >= 0 && fstart + N <= Li && base_aligned && !(fstart & 1)) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) dst[u] = *reinterpret_cast<const v2f *>(ap + 2 * u * TPF);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int s = fstart + 2 * (t + u * TPF);
+                dst[u].x = (s >= 0 && s < Li) ? ap[2 * u * TPF] : 0.f;
+                dst[u].y = (s + 1 >= 0 && s + 1 < Li) ? ap[2 * u * TPF + 1] : 0.f;
+            }
+        }
+    };
+
+    // this slot's frame sequence: groups g_first..g_end-1, FPS consecutive frames in each
+    const int n_seq = (g_end - g_first) * FPS;
+    // The first frame's samples are requested BEFORE the constant set-up below: a workgroup lives for only ~5 us and
+    // nothing can be prefetched for its first frame, so this HBM round trip (~2 us under load) is overlapped with the
+    // table copy, its two barriers and the 26 per-lane constant reads instead of following them.
+    v2f nx[8];
+    load_frame(g_first * FPB + slot * FPS, nx);
+
     // ---- per-thread constants, kept in registers over all the workgroup's frames.  The 10 KB table is copied
     // into LDS cooperatively (the [bin][frame] image is still unused) and each lane picks its 26 values from
     // there: 10 KB of L2->CU traffic per workgroup instead of 53 KB of per-lane gathers (the kernel is bound by
@@ -343,33 +374,6 @@ __global__ __launch_bounds__(NW * 64, WPE) void stft_wave_kernel(const float *__
     }
     __syncthreads();                                      // everyone holds its constants: the image may be written
 
-    const int Li = (int)L;                                // adn_stft_mag guarantees L < 2^30
-    const bool base_aligned = (reinterpret_cast<uintptr_t>(aud) & 7) == 0;
-
-    // raw (unwindowed) samples of frame `fidx` of this clip -> dst[8]
-    auto load_frame = [&](int fidx, v2f *dst) {
-        const int fstart = fidx * hop - pad;               // may be < 0 (centre padding) or run past the clip
-        const float *ap = aud + fstart + 2 * t;
-        if (ablate & 1) {                                  // timing experiment only: no audio traffic
-#pragma unroll
-            for (int u = 0; u < 8; ++u) dst[u] = v2f{(float)(fidx + u), 1.f};
-        } else if (fstart >= 0 && fstart + N <= Li && base_aligned && !(fstart & 1)) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) dst[u] = *reinterpret_cast<const v2f *>(ap + 2 * u * TPF);
-        } else {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int s = fstart + 2 * (t + u * TPF);
-                dst[u].x = (s >= 0 && s < Li) ? ap[2 * u * TPF] : 0.f;
-                dst[u].y = (s + 1 >= 0 && s + 1 < Li) ? ap[2 * u * TPF + 1] : 0.f;
-            }
-        }
-    };
-
-    // this slot's frame sequence: groups g_first..g_end-1, FPS consecutive frames in each
-    const int n_seq = (g_end - g_first) * FPS;
-    v2f nx[8];
-    load_frame(g_first * FPB + slot * FPS, nx);
     int g = g_first, fi = 0;
 #pragma unroll 1
     for (int it = 0; it < n_seq; ++it) {

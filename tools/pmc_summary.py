@@ -31,12 +31,42 @@ FAMILIES = {
     "convt_f32": lambda n: n.startswith("conv_mfma<float") and ", 1, 4, 2>" in n,
     "convt_f16": lambda n: n.startswith("conv_mfma<_Float16") and ", 1, 4, 2>" in n,
     "stft_wave_kernel": lambda n: n.startswith("stft_wave_kernel"),
-    "conv_first_kernel": lambda n: n.startswith("conv_first_kernel"),
-    "conv_out_kernel": lambda n: n.startswith("conv_out_kernel"),
+    "conv_first_kernel": lambda n: n.startswith("conv_first_kernel<float"),
+    "conv_out_kernel": lambda n: n.startswith("conv_out_kernel<float"),
+    "conv_first_kernel_f16": lambda n: n.startswith("conv_first_kernel<_Float16"),
+    "conv_out_kernel_f16": lambda n: n.startswith("conv_out_kernel<_Float16"),
 }
 
 
+def demangle_f16(name: str) -> str:
+    """rocprofv3 leaves names with _Float16 template arguments mangled (DF16_); rebuild `kernel<_Float16, 16, ...>`."""
+    m = re.match(r"_ZN3adn12_GLOBAL__N_1(\d+)", name)
+    if not m:
+        return name
+    n = int(m.group(1))
+    rest = name[m.end():]
+    kern, rest = rest[:n], rest[n:]
+    if not rest.startswith("I"):
+        return kern
+    args, i = [], 1
+    while i < len(rest) and rest[i] != "E":
+        if rest.startswith("DF16_", i):
+            args.append("_Float16")
+            i += 5
+        elif rest[i] == "f":
+            args.append("float")
+            i += 1
+        elif rest[i] == "L":                       # Li<digits>E
+            j = rest.index("E", i)
+            args.append(rest[i + 2:j])
+            i = j + 1
+        else:
+            break
+    return f"{kern}<{', '.join(args)}>"
+
+
 def short(name: str) -> str:
+    name = demangle_f16(name)
     name = name.replace("void ", "").replace("adn::(anonymous namespace)::", "")
     name = re.sub(r"\(.*\)$", "", name)
     return name[:90]
