@@ -28,6 +28,9 @@
 //   the accumulator registers (the four pixels of a pool window live in one lane by construction).
 #include "adn_internal.h"
 
+#include <atomic>
+#include <cstdlib>
+
 namespace adn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -50,6 +53,72 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg)
     const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
     const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return start + (b >> 3);
+}
+
+// Epilogue shared by the register-staged and the LDS-DMA kernels: folded-BN bias (+ ReLU, + 2x2 max-pool) or the
+// pixel-shuffle store of the transposed convolution.
+template <typename T, int TH, int BN, int WM, int WN, int EPI>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs &p, f32x16 (&acc)[TH * TW / 32 / WM][BN / 32 / WN],
+                                              const float (&bias_r)[BN / 32 / WN], int lane, int wave, int ct, int n, int ty,
+                                              int tx)
+{
+    constexpr int MB = TH * TW / 32 / WM, NB = BN / 32 / WN;
+    const int wm = wave / WN, wn = wave % WN;
+    const int hh = lane >> 5, l31 = lane & 31;
+    // ---- epilogue ----
+    // accumulator register r of lane (hh, l31): GEMM row m = (r&3) + 8*(r>>2) + 4*hh, column l31.
+    // row m of m-block i -> tile pixel (trow, tcol) = ((wm*MB+i)*2 + (m>>4), m&15).
+    T *outp = static_cast<T *>(p.out);
+    T *poolp = static_cast<T *>(p.pool);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int col = ct * BN + (wn * NB + j) * 32 + l31;     // GEMM column
+        const float bv = bias_r[j];
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            const int trow0 = (wm * MB + i) * 2;
+            if (EPI == CONVT2X2) {
+                // column = (di*2+dj)*Cout + co ; output pixel (2*gy+di, 2*gx+dj); bias only, no activation.
+                const int ij = col / p.Cout, co = col - ij * p.Cout;
+                const int Ho = 2 * p.H, Wo = 2 * p.W;
+                T *ob = outp + (size_t)n * Ho * Wo * p.Cout + co;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    const int gy = ty * TH + trow0 + (m >> 4), gx = tx * TW + (m & 15);
+                    if (gy < p.H && gx < p.W)
+                        ob[((size_t)(2 * gy + (ij >> 1)) * Wo + (2 * gx + (ij & 1))) * p.Cout] = (T)(acc[i][j][r] + bv);
+                }
+            } else {
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc[i][j][r] + bv, 0.f);
+                T *ob = outp + (size_t)n * p.H * p.W * p.Cout + col;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    const int gy = ty * TH + trow0 + (m >> 4), gx = tx * TW + (m & 15);
+                    if (gy < p.H && gx < p.W) ob[((size_t)gy * p.W + gx) * p.Cout] = (T)v[r];
+                }
+                if (EPI == CONV3X3_RELU_POOL) {
+                    // 2x2 window (rows trow0, trow0+1; cols tcol, tcol+1 with tcol even) = registers
+                    // (q,pp), (q,pp+1), (q+2,pp), (q+2,pp+1) with r = 4q+pp, q in {0,1}, pp in {0,2}.
+                    const int Hp = p.H >> 1, Wp = p.W >> 1;
+                    T *pb = poolp + (size_t)n * Hp * Wp * p.Cout + col;
+                    const int py = (ty * TH + trow0) >> 1;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int pp = 0; pp < 4; pp += 2) {
+                            const float m4 = fmaxf(fmaxf(v[4 * q + pp], v[4 * q + pp + 1]),
+                                                   fmaxf(v[4 * (q + 2) + pp], v[4 * (q + 2) + pp + 1]));
+                            const int px = ((tx * TW) >> 1) + (pp >> 1) + 2 * hh + 4 * q;
+                            if (py < Hp && px < Wp) pb[((size_t)py * Wp + px) * p.Cout] = (T)m4;
+                        }
+                }
+            }
+        }
+    }
 }
 
 template <typename T, int TH, int BN, int WM, int WN, int TAPS, int KG, int EPI>
@@ -206,60 +275,176 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 4) void conv_mfm
     }
 #undef ADN_PREFETCH
 
-    // ---- epilogue ----
-    // accumulator register r of lane (hh, l31): GEMM row m = (r&3) + 8*(r>>2) + 4*hh, column l31.
-    // row m of m-block i -> tile pixel (trow, tcol) = ((wm*MB+i)*2 + (m>>4), m&15).
-    T *outp = static_cast<T *>(p.out);
-    T *poolp = static_cast<T *>(p.pool);
+    conv_epilogue<T, TH, BN, WM, WN, EPI>(p, acc, bias_r, lane, wave, ct, n, ty, tx);
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv_dma<T>: the same implicit GEMM with LDS-DMA staging (global_load_lds_dwordx4: global -> LDS, no VGPR staging,
+// no ds_write pass) into one of two LDS images while the other is consumed; one barrier per K-chunk.  Used where the
+// register-staged kernel is bound by its copies: the fp16 path (16x faster matrix cores, same CU ingest path; the
+// register staging also cost 28 VGPRs and spilled under the 128-VGPR budget of two 8-wave workgroups per CU) and the
+// transposed convolutions.
+//   LDS image = consecutive 16-byte slots; wave-instruction k of a copy fills slots [k*NT + 64*wave, +64):
+//     A (halo): KG == 1: row = PW pixels x 2 slots + ONE pad slot per row (conflict-free ds_read_b128: a read group holds
+//               two tile rows, whose bases then differ by 4 dwords mod 8);  KG > 1: pixel = 2*KG slots + one pad slot.
+//               Pad and out-of-image slots are copied from a 16-byte block of zeros (the convolution's zero padding).
+//               The A part is padded to a multiple of 64 slots so that every wave-instruction is wholly A or wholly B.
+//     B (weights): the packed slab of the chunk, a linear copy.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int TH, int BN, int WM, int WN, int TAPS, int KG>
+struct DmaCfg {
+    static constexpr int NT = 64 * WM * WN;
+    static constexpr int HALO = (TAPS == 9) ? 1 : 0;
+    static constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
+    static constexpr int KQ = 2 * KG;                                  // data slots per pixel
+    static constexpr int PSLOT = (KG == 1) ? KQ : KQ + 1;              // slots per pixel
+    static constexpr int RSLOT = PW * PSLOT + ((KG == 1) ? 1 : 0);     // slots per halo row
+    static constexpr int A_USED = PH * RSLOT;
+    static constexpr int A_SLOTS = (A_USED + 63) / 64 * 64;
+    static constexpr int B_SLOTS = TAPS * KG * 2 * BN;
+    static constexpr int SLOTS = A_SLOTS + B_SLOTS;                    // per image
+    static constexpr int NPIECE = (SLOTS + NT - 1) / NT;               // wave-instructions per thread and chunk
+    static constexpr int A_ROUNDS = (A_SLOTS + NT - 1) / NT;           // of which may carry halo slots
+    static constexpr size_t LDS_BYTES = (size_t)2 * SLOTS * 16;
+    static_assert(B_SLOTS % 64 == 0, "weight slab must be a whole number of wave copies");
+};
+
+__device__ __forceinline__ void conv_dma16(const void *g, float *lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+template <typename T, int TH, int BN, int WM, int WN, int TAPS, int KG, int EPI, int WPE>
+__global__ __launch_bounds__(64 * WM * WN, WPE) void conv_dma(const ConvArgs p)
+{
+    using C = DmaCfg<T, TH, BN, WM, WN, TAPS, KG>;
+    constexpr int NT = C::NT, EPV = Elem<T>::EPV, HALO = C::HALO, PW = C::PW;
+    constexpr int KC = 2 * EPV * KG;
+    constexpr int PSLOT = C::PSLOT, RSLOT = C::RSLOT, A_SLOTS = C::A_SLOTS, SLOTS = C::SLOTS, NPIECE = C::NPIECE;
+    constexpr int A_ROUNDS = C::A_ROUNDS;
+    constexpr int B_DW = C::B_SLOTS * 4;                               // floats (dwords) of one chunk's weight slab
+    constexpr int MB = TH * TW / 32 / WM, NB = BN / 32 / WN;
+    static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves per workgroup");
+    static_assert(MB >= 1 && NB >= 1, "tile too small");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];       // two images of SLOTS x 16 bytes
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);         // provably wave-uniform (DMA base, A/B split)
+    const int wm = wave / WN, wn = wave % WN;
+    const int hh = lane >> 5, l31 = lane & 31;
+
+    int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int ct = lid % p.nct;
+    lid /= p.nct;
+    const int tx = lid % p.tilesX;
+    lid /= p.tilesX;
+    const int ty = lid % p.tilesY;
+    const int n = lid / p.tilesY;
+    const int gy0 = ty * TH - HALO, gx0 = tx * TW - HALO;
+
+    // ---- DMA plan (fixed over the chunk loop): halo slot s = r*NT + tid -> source element offset, -1 = zeros ----
+    int hcur[A_ROUNDS], hsec[A_ROUNDS];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        const int col = ct * BN + (wn * NB + j) * 32 + l31;     // GEMM column
-        const float bv = bias_r[j];
+    for (int r = 0; r < A_ROUNDS; ++r) {
+        const int s = r * NT + tid;
+        const int row = s / RSLOT, k = s - row * RSLOT;
+        const int pix = k / PSLOT, q = k - pix * PSLOT;
+        const bool data = s < C::A_USED && pix < PW && q < C::KQ;
+        const int gy = gy0 + row, gx = gx0 + pix;
+        const int y0 = gy - p.s0.offY, x0 = gx - p.s0.offX;
+        hcur[r] = (data && y0 >= 0 && y0 < p.s0.H && x0 >= 0 && x0 < p.s0.W) ? (y0 * p.s0.W + x0) * p.s0.C + q * EPV : -1;
+        const int y1 = gy - p.s1.offY, x1 = gx - p.s1.offX;
+        hsec[r] = (data && y1 >= 0 && y1 < p.s1.H && x1 >= 0 && x1 < p.s1.W) ? (y1 * p.s1.W + x1) * p.s1.C + q * EPV : -1;
+    }
+    const T *srcp = static_cast<const T *>(p.s0.ptr) + (size_t)n * p.s0.H * p.s0.W * p.s0.C;   // next chunk's channels
+    const T *base1 = static_cast<const T *>(p.s1.ptr) + (size_t)n * p.s1.H * p.s1.W * p.s1.C;
+    const float *wp = static_cast<const float *>(p.wpk) + (size_t)ct * p.nchunk * B_DW;            // next chunk's slab
+    const float *zsrc = p.zeros;
+
+    // copy of chunk `c` into image `buf`: NPIECE wave-instructions per thread
+    auto dma_chunk = [&](int c, int buf) {
+        if (c == p.nchunk0) {                          // wave-uniform: switch to the second source (virtual concat)
+            srcp = base1;
 #pragma unroll
-        for (int i = 0; i < MB; ++i) {
-            const int trow0 = (wm * MB + i) * 2;
-            if (EPI == CONVT2X2) {
-                // column = (di*2+dj)*Cout + co ; output pixel (2*gy+di, 2*gx+dj); bias only, no activation.
-                const int ij = col / p.Cout, co = col - ij * p.Cout;
-                const int Ho = 2 * p.H, Wo = 2 * p.W;
-                T *ob = outp + (size_t)n * Ho * Wo * p.Cout + co;
+            for (int r = 0; r < A_ROUNDS; ++r) hcur[r] = hsec[r];
+        }
+        float *img = smem + (size_t)buf * SLOTS * 4;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    const int gy = ty * TH + trow0 + (m >> 4), gx = tx * TW + (m & 15);
-                    if (gy < p.H && gx < p.W)
-                        ob[((size_t)(2 * gy + (ij >> 1)) * Wo + (2 * gx + (ij & 1))) * p.Cout] = (T)(acc[i][j][r] + bv);
-                }
+        for (int k = 0; k < NPIECE; ++k) {
+            const int sb = k * NT + wave * 64;          // first slot of this wave-instruction (uniform)
+            if (sb >= SLOTS) continue;                   // tail of the last piece
+            float *dst = img + sb * 4;
+            if (k < A_ROUNDS && sb < A_SLOTS) {
+                const int off = hcur[k < A_ROUNDS ? k : 0];
+                conv_dma16(off >= 0 ? static_cast<const void *>(srcp + off) : static_cast<const void *>(zsrc), dst);
             } else {
-                float v[16];
+                conv_dma16(wp + (size_t)(sb - A_SLOTS + lane) * 4, dst);
+            }
+        }
+        srcp += KC;
+        wp += B_DW;
+    };
+
+    float bias_r[NB];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc[i][j][r] + bv, 0.f);
-                T *ob = outp + (size_t)n * p.H * p.W * p.Cout + col;
+    for (int j = 0; j < NB; ++j) bias_r[j] = p.bias[ct * BN + (wn * NB + j) * 32 + l31];
+
+    f32x16 acc[MB][NB];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    const int gy = ty * TH + trow0 + (m >> 4), gx = tx * TW + (m & 15);
-                    if (gy < p.H && gx < p.W) ob[((size_t)gy * p.W + gx) * p.Cout] = (T)v[r];
-                }
-                if (EPI == CONV3X3_RELU_POOL) {
-                    // 2x2 window (rows trow0, trow0+1; cols tcol, tcol+1 with tcol even) = registers
-                    // (q,pp), (q,pp+1), (q+2,pp), (q+2,pp+1) with r = 4q+pp, q in {0,1}, pp in {0,2}.
-                    const int Hp = p.H >> 1, Wp = p.W >> 1;
-                    T *pb = poolp + (size_t)n * Hp * Wp * p.Cout + col;
-                    const int py = (ty * TH + trow0) >> 1;
+    for (int i = 0; i < MB; ++i)
 #pragma unroll
-                    for (int q = 0; q < 2; ++q)
+        for (int j = 0; j < NB; ++j)
 #pragma unroll
-                        for (int pp = 0; pp < 4; pp += 2) {
-                            const float m4 = fmaxf(fmaxf(v[4 * q + pp], v[4 * q + pp + 1]),
-                                                   fmaxf(v[4 * (q + 2) + pp], v[4 * (q + 2) + pp + 1]));
-                            const int px = ((tx * TW) >> 1) + (pp >> 1) + 2 * hh + 4 * q;
-                            if (py < Hp && px < Wp) pb[((size_t)py * Wp + px) * p.Cout] = (T)m4;
-                        }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // LDS read bases (dwords)
+    const int a_lane = ((wm * MB * 2 + ((lane >> 4) & 1)) * RSLOT + (lane & 15) * PSLOT) * 4 + hh * 4;
+    const int b_lane = A_SLOTS * 4 + hh * BN * 4 + (wn * NB * 32 + l31) * 4;
+
+    dma_chunk(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int c = 0; c < p.nchunk; ++c) {
+        if (c + 1 < p.nchunk) dma_chunk(c + 1, (c + 1) & 1);          // lands under the MFMAs below
+        const float *img = smem + (size_t)(c & 1) * SLOTS * 4;
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int dy = (TAPS == 9) ? tap / 3 : 0, dx = (TAPS == 9) ? tap % 3 : 0;
+#pragma unroll
+            for (int s = 0; s < KG; ++s) {
+                f32x4 a[MB], b[NB];
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+                    a[i] = *reinterpret_cast<const f32x4 *>(img + a_lane + ((i * 2 + dy) * RSLOT + dx * PSLOT) * 4 + s * 8);
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    b[j] = *reinterpret_cast<const f32x4 *>(img + b_lane + j * 128 + (tap * KG + s) * 2 * BN * 4);
+                if constexpr (sizeof(T) == 4) {
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                        for (int i = 0; i < MB; ++i)
+#pragma unroll
+                            for (int j = 0; j < NB; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], b[j][kk], acc[i][j], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < MB; ++i)
+#pragma unroll
+                        for (int j = 0; j < NB; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[i]),
+                                                                               __builtin_bit_cast(f16x8, b[j]), acc[i][j], 0, 0, 0);
                 }
             }
         }
+        // every wave: its own copies have landed (vmcnt) ; then all waves: image c is free, image c+1 complete
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     }
+    conv_epilogue<T, TH, BN, WM, WN, EPI>(p, acc, bias_r, lane, wave, ct, n, ty, tx);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -391,22 +576,63 @@ hipError_t launch_cfg(const ConvArgs &a, hipStream_t st)
     return hipGetLastError();
 }
 
+template <typename T, int TH, int BN, int WM, int WN, int TAPS, int KG, int EPI, int WPE>
+hipError_t launch_dma_cfg(const ConvArgs &a, hipStream_t st)
+{
+    using C = DmaCfg<T, TH, BN, WM, WN, TAPS, KG>;
+    const long nwg = (long)a.N * a.tilesY * a.tilesX * a.nct;
+    if (nwg <= 0 || nwg > 0x7fffffffL || !a.zeros) return hipErrorInvalidValue;
+    auto kern = conv_dma<T, TH, BN, WM, WN, TAPS, KG, EPI, WPE>;
+    if (C::LDS_BYTES > 64 * 1024) {
+        // the attribute is per device: remember which devices of this process have it
+        static std::atomic<unsigned long long> attr_mask{0};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(attr_mask.load(std::memory_order_acquire) & bit)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+            if (e != hipSuccess) return e;
+            attr_mask.fetch_or(bit, std::memory_order_release);
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(C::NT), C::LDS_BYTES, st, a);
+    return hipGetLastError();
+}
+
+// true: register-staged kernels everywhere (A/B runs of an experiments build only)
+inline bool staging_regs()
+{
+#ifdef ADN_EXPERIMENTS
+    static const bool regs = []() { const char *e = std::getenv("ADN_CONV_STAGING"); return e && e[0] == 'r'; }();
+    return regs;
+#else
+    return false;
+#endif
+}
+
 template <typename T>
 hipError_t launch_conv_mfma_t(ConvKind kind, const ConvArgs &a, hipStream_t st)
 {
     if constexpr (sizeof(T) == 2) {
         // fp16: the matrix cores are 16x faster than for fp32 while the CU's ingest path is not, so the kernel is
-        // bound by the bytes staged per FLOP; 8-wave workgroups on 2x larger pixel tiles amortise the weight slab
-        // over twice the pixels (same accumulator count per wave).
-        if (kind == CONVT2X2) return launch_cfg<T, 16, 128, 4, 2, 1, 4, CONVT2X2>(a, st);
-        if (a.Cout == 64) {
+        // bound by the bytes staged per FLOP: LDS-DMA staging, and 8-wave workgroups on 32x16-pixel tiles x 64 couts
+        // (132 staged bytes per MFMA; 16x16 px x 128 couts would be 164), two workgroups per CU.
+        if (kind == CONVT2X2) {
+            if (staging_regs()) return launch_cfg<T, 8, 128, 2, 2, 1, 4, CONVT2X2>(a, st);
+            return launch_dma_cfg<T, 8, 128, 2, 2, 1, 4, CONVT2X2, 2>(a, st);
+        }
+        if (staging_regs()) {
             if (kind == CONV3X3_RELU_POOL) return launch_cfg<T, 32, 64, 8, 1, 9, 1, CONV3X3_RELU_POOL>(a, st);
             return launch_cfg<T, 32, 64, 8, 1, 9, 1, CONV3X3_RELU>(a, st);
         }
-        if (kind == CONV3X3_RELU_POOL) return launch_cfg<T, 16, 128, 4, 2, 9, 1, CONV3X3_RELU_POOL>(a, st);
-        return launch_cfg<T, 16, 128, 4, 2, 9, 1, CONV3X3_RELU>(a, st);
+        if (kind == CONV3X3_RELU_POOL) return launch_dma_cfg<T, 32, 64, 8, 1, 9, 1, CONV3X3_RELU_POOL, 4>(a, st);
+        return launch_dma_cfg<T, 32, 64, 8, 1, 9, 1, CONV3X3_RELU, 4>(a, st);
     } else {
-        if (kind == CONVT2X2) return launch_cfg<T, 8, 128, 2, 2, 1, 4, CONVT2X2>(a, st);
+        if (kind == CONVT2X2) {
+            if (staging_regs()) return launch_cfg<T, 8, 128, 2, 2, 1, 4, CONVT2X2>(a, st);
+            return launch_dma_cfg<T, 8, 128, 2, 2, 1, 4, CONVT2X2, 2>(a, st);
+        }
         if (a.Cout == 64) {
             if (kind == CONV3X3_RELU_POOL) return launch_cfg<T, 16, 64, 4, 1, 9, 1, CONV3X3_RELU_POOL>(a, st);
             return launch_cfg<T, 16, 64, 4, 1, 9, 1, CONV3X3_RELU>(a, st);
@@ -422,10 +648,10 @@ hipError_t launch_conv_mfma_t(ConvKind kind, const ConvArgs &a, hipStream_t st)
 ConvGeom conv_geom(ConvKind kind, int Cout, bool f16)
 {
     const int cpg = f16 ? 16 : 8;                // channels per k-group
-    const int th = f16 ? 2 : 1;                  // fp16 tiles are twice as tall (8-wave workgroups)
-    if (kind == CONVT2X2) return ConvGeom{8 * th, 128, 4 * cpg};
-    if (Cout == 64) return ConvGeom{16 * th, 64, cpg};
-    return ConvGeom{8 * th, 128, cpg};
+    if (kind == CONVT2X2) return ConvGeom{8, 128, 4 * cpg};
+    if (f16) return ConvGeom{32, 64, cpg};       // fp16 3x3: 32x16-pixel tiles x 64 couts for every layer
+    if (Cout == 64) return ConvGeom{16, 64, cpg};
+    return ConvGeom{8, 128, cpg};
 }
 
 hipError_t launch_conv_mfma(ConvKind kind, const ConvArgs &a, bool f16, hipStream_t st)
