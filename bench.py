@@ -191,7 +191,7 @@ def forward_summary(ms_mean, b, algo, peak):
             "per_launch_ms": {l["name"]: round(float(m), 4) for l, m in zip(launches, ms_mean)}}
 
 
-def bench_stft(dev, clips=10000, length=132300, n_fft=1024, hop=256, steps=20, warmup=3, cpu_clips=64):
+def bench_stft(dev, clips=10000, length=132300, n_fft=1024, hop=256, steps=20, warmup=3, cpu_clips=4096):
     """BASELINE configs[2] on one GPU; inputs resident in HBM; events on the launch stream (torch's current stream)."""
     from audiodenoiser_amd import _lib
     from audiodenoiser_amd.stft import stft_n_frames
@@ -225,7 +225,7 @@ def bench_stft(dev, clips=10000, length=132300, n_fft=1024, hop=256, steps=20, w
            "dtype": "f32",
            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
                         "frac": round(gbs / 8000.0, 4), "traffic": traffic, "traffic_source": source,
-                        "kernel": "stft_wave_kernel<512,4,16>, 1 launch per step",
+                        "kernel": "stft_wave_kernel<512,4,16,3>, 1 launch per step",
                         "algorithmic_bytes_per_launch": clips * bytes_per_clip, "bytes_per_clip": bytes_per_clip}}
     if cpu_clips > 0:
         import oracle
@@ -374,7 +374,7 @@ def main() -> None:
         if world == 1 and not args.no_extras:
             net._workspace = None
             torch.cuda.empty_cache()
-            out["stft"] = bench_stft(dev, steps=args.stft_steps, cpu_clips=0 if args.no_stft_cpu else 64)
+            out["stft"] = bench_stft(dev, steps=args.stft_steps, cpu_clips=0 if args.no_stft_cpu else 4096)
             if not f16:
                 out["f16"] = bench_f16(sd_np, dev, steps=args.f16_steps)
         if not args.no_cpu_baseline and world == 1:

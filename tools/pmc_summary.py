@@ -27,9 +27,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FAMILIES = {
     "wino_conv_dma_f32": lambda n: n.startswith("wino_conv_dma_f32"),
     "conv_mfma_f32": lambda n: n.startswith("conv_mfma<float") and ", 9, " in n,
-    "conv_mfma_f16": lambda n: n.startswith("conv_mfma<_Float16") and ", 9, " in n,
-    "convt_f32": lambda n: n.startswith("conv_mfma<float") and ", 1, 4, 2>" in n,
-    "convt_f16": lambda n: n.startswith("conv_mfma<_Float16") and ", 1, 4, 2>" in n,
+    "conv_mfma_f16": lambda n: n.startswith(("conv_mfma<_Float16", "conv_dma<_Float16")) and ", 9, " in n,
+    "convt_f32": lambda n: n.startswith(("conv_mfma<float", "conv_dma<float")) and ", 1, 4, 2" in n,
+    "convt_f16": lambda n: n.startswith(("conv_mfma<_Float16", "conv_dma<_Float16")) and ", 1, 4, 2" in n,
     "stft_wave_kernel": lambda n: n.startswith("stft_wave_kernel"),
     "conv_first_kernel": lambda n: n.startswith("conv_first_kernel<float"),
     "conv_out_kernel": lambda n: n.startswith("conv_out_kernel<float"),
