@@ -267,6 +267,8 @@ adn::ConvArgs conv_args(const adn_unet *h, const Conv3x3Layer &L, adn::ConvKind 
     a.ksplit = 1;
     a.nwg_base = 0;
     a.partial = nullptr;
+    a.dotw = nullptr;
+    a.dot_out = nullptr;
     return a;
 }
 
@@ -274,7 +276,7 @@ hipError_t launch_conv3(const adn_unet *h, adn::ConvKind kind, const adn::ConvAr
 {
     if (!h->use_wino) return adn::launch_conv_mfma(kind, a, h->f16, st);
     adn::ConvArgs a2 = a;
-    a2.ksplit = h->allow_split ? adn::wino_ksplit(adn::wino_workgroups(a), a.nchunk) : 1;
+    a2.ksplit = (h->allow_split && kind != adn::CONV3X3_RELU_DOT) ? adn::wino_ksplit(adn::wino_workgroups(a), a.nchunk) : 1;
     a2.partial = partial;
     return adn::launch_wino_conv(kind, a2, st);
 }
@@ -351,6 +353,7 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
     // ---- up path (model.py:84-91): convT -> (virtual) pad + cat([skip, up]) -> DoubleConv ----
     void *X = tB, *Y = tA;   // X holds the current tensor
     int uh = p.H[4], uw = p.W[4], upc = 1024;
+    bool fused_out = false;
     for (int l = 3; l >= 0; --l) {
         const int co = CH[l];
         const ConvTLayer &TL = h->ct[3 - l];
@@ -376,6 +379,8 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
         t.ksplit = 1;
         t.nwg_base = 0;
         t.partial = nullptr;
+        t.dotw = nullptr;
+        t.dot_out = nullptr;
         ADN_MARK();
         ADN_HIP(adn::launch_conv_mfma(adn::CONVT2X2, t, f16, st));
         // first conv of the DoubleConv reads cat([skip, x1]) virtually
@@ -385,8 +390,16 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
         ADN_HIP(launch_conv3(h, adn::CONV3X3_RELU, a, part, st));
         ++li;
         adn::ConvArgs b = conv_args(h, h->c3[li], adn::CONV3X3_RELU, X, co, nullptr, 0, 0, 0, Y, nullptr, N, p.H[l], p.W[l]);
+        // The network's last two layers (up4's second conv3x3 and the 1x1 output convolution, model.py:91,93) run fused
+        // on the Winograd path: the 64-channel tensor between them is never written (Y holds the two partial planes
+        // instead).  Not when block outputs are exported (the up4 tap IS that tensor).
+        fused_out = l == 0 && h->use_wino && !taps && b.nct == 2;
+        if (fused_out) {
+            b.dotw = h->dev + h->out_w;
+            b.dot_out = static_cast<float *>(Y);
+        }
         ADN_MARK();
-        ADN_HIP(launch_conv3(h, adn::CONV3X3_RELU, b, part, st));
+        ADN_HIP(launch_conv3(h, fused_out ? adn::CONV3X3_RELU_DOT : adn::CONV3X3_RELU, b, part, st));
         ++li;
         ADN_HIP(export_tap(5 + (3 - l), Y, co, p.H[l], p.W[l]));
         void *tmp = X;
@@ -398,7 +411,10 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
     }
     // ---- 1x1 output convolution (model.py:93) ----
     ADN_MARK();
-    ADN_HIP(adn::launch_conv_out(X, f16, h->dev + h->out_w, h->out_b, y, (long)N * F * T, st));
+    if (fused_out)      // X = the buffer the fused layer wrote its partial planes to (the loop swapped X and Y)
+        ADN_HIP(adn::launch_dot_finish(static_cast<const float *>(X), 2, h->out_b, y, (long)N * F * T, st));
+    else
+        ADN_HIP(adn::launch_conv_out(X, f16, h->dev + h->out_w, h->out_b, y, (long)N * F * T, st));
     ADN_MARK();
     if (timed) {
         if (evi != ADN_N_LAUNCHES + 1) return fail(ADN_ERR_INVALID, "internal: launch count mismatch");

@@ -35,6 +35,9 @@ struct ConvArgs {
     int ksplit;
     int nwg_base;          // workgroups per split (grid = nwg_base * ksplit)
     float *partial;
+    // CONV3X3_RELU_DOT: weights of the fused 1x1 convolution (Cout floats) and its partial planes [nct][N][H][W]
+    const float *dotw;
+    float *dot_out;
 };
 
 // Number of K splits for a 3x3 layer launched as `nwg` Winograd workgroups of `nchunk` chunks: only when the grid
@@ -46,7 +49,11 @@ inline int wino_ksplit(long nwg, int nchunk)
     return ks;
 }
 
-enum ConvKind { CONV3X3_RELU = 0, CONV3X3_RELU_POOL = 1, CONVT2X2 = 2 };
+// CONV3X3_RELU_DOT (Winograd kernel only): conv3x3 + BN + ReLU whose 64-channel result is never written; instead every
+// workgroup contracts its 32 output channels with the weights of the following 1x1 convolution (reference model.py:68,93,
+// the network's last layer) and stores one float per pixel into plane `ct` of ConvArgs::dot_out; launch_dot_finish adds
+// the planes and the bias.  Saves the 64-channel tensor's HBM round trip (write + read of N*H*W*64 floats).
+enum ConvKind { CONV3X3_RELU = 0, CONV3X3_RELU_POOL = 1, CONVT2X2 = 2, CONV3X3_RELU_DOT = 3 };
 
 // Tile geometry chosen per layer (must match the weight packing).
 struct ConvGeom {
@@ -66,6 +73,8 @@ long wino_workgroups(const ConvArgs &a);
 // First layer: Conv2d(1 -> 64, 3x3, pad 1) + folded BN + ReLU, fp32 input, NHWC output.  w9x64: [tap][cout].
 hipError_t launch_conv_first(const float *x, const float *w9x64, const float *bias, void *out, bool f16,
                              int N, int H, int W, hipStream_t st);
+// y[i] = bias + sum over `planes` partial planes of CONV3X3_RELU_DOT (fixed order): the tail of the fused last layer.
+hipError_t launch_dot_finish(const float *planes, int nplanes, float bias, float *y, long npix, hipStream_t st);
 // Last layer: Conv2d(64 -> 1, 1x1), fp32 output.
 hipError_t launch_conv_out(const void *in, bool f16, const float *w64, float bias, float *out, long npix, hipStream_t st);
 // NHWC -> NCHW fp32 (parity-test export only).

@@ -541,6 +541,19 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const T *__restrict__ in,
     }
 }
 
+// Tail of the fused last layer (CONV3X3_RELU_DOT): y = bias + plane 0 + plane 1 (+ ...), fixed order.  HBM-bound and
+// tiny (2 + 1 floats per pixel instead of the 64 + 1 of conv_out_kernel).
+__global__ __launch_bounds__(256) void dot_finish_kernel(const float *__restrict__ planes, int nplanes, float bias,
+                                                         float *__restrict__ y, long npix)
+{
+    const long step = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < npix; i += step) {
+        float s = bias;
+        for (int k = 0; k < nplanes; ++k) s += planes[(size_t)k * npix + i];
+        y[i] = s;
+    }
+}
+
 // NHWC (T) -> NCHW (fp32) through a 32x33 LDS tile (parity-test export only).
 template <typename T>
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T *__restrict__ in, float *__restrict__ out,
@@ -691,6 +704,15 @@ hipError_t launch_conv_out(const void *in, bool f16, const float *w64, float bia
     else
         hipLaunchKernelGGL(conv_out_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st,
                            static_cast<const float *>(in), w64, bias, out, npix);
+    return hipGetLastError();
+}
+
+hipError_t launch_dot_finish(const float *planes, int nplanes, float bias, float *y, long npix, hipStream_t st)
+{
+    long blocks = (npix + 255) / 256;
+    if (blocks > 256L * 16) blocks = 256L * 16;
+    if (blocks < 1 || nplanes < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(dot_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, st, planes, nplanes, bias, y, npix);
     return hipGetLastError();
 }
 

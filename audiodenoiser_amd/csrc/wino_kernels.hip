@@ -356,6 +356,45 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
         o[6] = (unsigned long long)nloc;
     }
 
+    if constexpr (EPI == CONV3X3_RELU_DOT) {
+        // Fused last layer: out[px] += sum over this workgroup's 32 couts of w1x1[c] * ReLU(conv[c][px] + bias[c]).
+        // Lane (q, ti) holds couts 16j + ti of the 2x2 pixels of tiles 4q .. 4q+3: it forms its two-channel partial dot
+        // per pixel, the 16 lanes' partials meet in LDS ([pixel][17], the images are free after the loop's last barrier)
+        // and thread p adds the 16 partials of pixel p in a fixed order: deterministic, no atomics.
+        static_assert(NW == 4 && SPLIT == 0, "fused 1x1 epilogue: 4-wave unsplit kernel only");
+        const float w0 = p.dotw[ct * WBN + ti], w1 = p.dotw[ct * WBN + 16 + ti];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int tile = 4 * q + r;
+            const int tyw = 2 * wr + (tile >> 3), txw = tile & 7;
+            float v[2][2][2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float s0[4], s1[4];
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    s0[x] = acc[j][4 * x + 0][r] + acc[j][4 * x + 1][r] + acc[j][4 * x + 2][r];
+                    s1[x] = acc[j][4 * x + 1][r] - acc[j][4 * x + 2][r] - acc[j][4 * x + 3][r];
+                }
+                v[j][0][0] = fmaxf(s0[0] + s0[1] + s0[2] + bias_r[j], 0.f);
+                v[j][1][0] = fmaxf(s0[1] - s0[2] - s0[3] + bias_r[j], 0.f);
+                v[j][0][1] = fmaxf(s1[0] + s1[1] + s1[2] + bias_r[j], 0.f);
+                v[j][1][1] = fmaxf(s1[1] - s1[2] - s1[3] + bias_r[j], 0.f);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    smem[((2 * tyw + a) * WT + 2 * txw + b) * 17 + ti] = w0 * v[0][a][b] + w1 * v[1][a][b];
+        }
+        __syncthreads();
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sum += smem[tid * 17 + i];
+        const int gy = ty * WT + (tid >> 4), gx = tx * WT + (tid & 15);
+        if (gy < p.H && gx < p.W) p.dot_out[(((size_t)ct * p.N + n) * p.H + gy) * p.W + gx] = sum;
+        return;
+    }
     const int Hp = p.H >> 1, Wp = p.W >> 1;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -475,6 +514,11 @@ hipError_t launch_wino_dma_n(ConvKind kind, const ConvArgs &a, hipStream_t st)
         if (e1 != hipSuccess) return e1;
         if (e2 != hipSuccess) return e2;
         if (e3 != hipSuccess) return e3;
+        if constexpr (NW == 4) {
+            e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_conv_dma_f32<CONV3X3_RELU_DOT, 4, 0>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e1 != hipSuccess) return e1;
+        }
         attr_mask.fetch_or(bit, std::memory_order_release);
     }
     a2.dbg = nullptr;
@@ -489,6 +533,7 @@ hipError_t launch_wino_dma_n(ConvKind kind, const ConvArgs &a, hipStream_t st)
         (void)hipMemsetAsync(a2.dbg, 0, dbg_bytes, st);
     }
     hipError_t le;
+    if (a2.ksplit > 1 && kind == CONV3X3_RELU_DOT) return hipErrorInvalidValue;      // the fused layer is never split
     if (a2.ksplit > 1) {
         // split-K: raw partial sums first (the epilogue variant does not matter), then sum + bias + ReLU (+ pool)
         if (!a2.partial || a2.nchunk % a2.ksplit || (a2.Cout & 3)) return hipErrorInvalidValue;
@@ -509,7 +554,14 @@ hipError_t launch_wino_dma_n(ConvKind kind, const ConvArgs &a, hipStream_t st)
                                a2.Cout);
         return hipGetLastError();
     }
-    if (kind == CONV3X3_RELU_POOL)
+    if (kind == CONV3X3_RELU_DOT) {
+        if constexpr (NW == 4) {
+            if (!a2.dotw || !a2.dot_out) return hipErrorInvalidValue;
+            hipLaunchKernelGGL((wino_conv_dma_f32<CONV3X3_RELU_DOT, 4, 0>), dim3((unsigned)nwg), dim3(256), lds, st, a2);
+        } else {
+            return hipErrorInvalidValue;
+        }
+    } else if (kind == CONV3X3_RELU_POOL)
         hipLaunchKernelGGL((wino_conv_dma_f32<CONV3X3_RELU_POOL, NW, 0>), dim3((unsigned)nwg), dim3(64 * NW), lds, st, a2);
     else
         hipLaunchKernelGGL((wino_conv_dma_f32<CONV3X3_RELU, NW, 0>), dim3((unsigned)nwg), dim3(64 * NW), lds, st, a2);

@@ -21,19 +21,18 @@ def executed_mfma_flops(launch: dict, algo: str) -> float:
 
     ``algo``: "winograd" (wino_conv_dma_f32: 16x16-pixel tiles, F(2x2,3x3) = 16 multiply-adds per 2x2 output tile and
     (cin, cout) pair instead of 36, i.e. 8 FLOP per padded output pixel and channel pair), "direct" (conv_mfma<float>:
-    TH x 16 tiles with TH = 16 for the 64-channel layers and 8 otherwise) or "direct_f16" (conv_mfma<_Float16>: tiles
-    twice as tall).  Transposed convolutions always run the direct kernel: K = Cin, 4*Cout GEMM columns, tiles of
-    input pixels.  The first (Cin = 1) and last (1x1, Cout = 1) layers do not use the matrix cores: 0."""
+    TH x 16 tiles with TH = 16 for the 64-channel layers and 8 otherwise) or "direct_f16" (conv_dma<_Float16>: 32 x 16
+    tiles for every layer).  Transposed convolutions run conv_dma<T, 8, 128, ...>: K = Cin, 4*Cout GEMM columns, 8 x 16
+    tiles of input pixels.  The first (Cin = 1) and last (1x1, Cout = 1) layers do not use the matrix cores: 0."""
     kind = launch["kind"]
     if kind in ("first", "out"):
         return 0.0
     cin, cout, h, w = launch["cin"], launch["cout"], launch["h"], launch["w"]
-    th2 = 2 if algo == "direct_f16" else 1
     if kind == "convt":
-        return 2.0 * cin * 4 * cout * _ceil_to(h, 8 * th2) * _ceil_to(w, 16)
+        return 2.0 * cin * 4 * cout * _ceil_to(h, 8) * _ceil_to(w, 16)
     if algo == "winograd":
         return 8.0 * cin * cout * _ceil_to(h, 16) * _ceil_to(w, 16)
-    th = (16 if cout == 64 else 8) * th2
+    th = 32 if algo == "direct_f16" else (16 if cout == 64 else 8)
     return 18.0 * cin * cout * _ceil_to(h, th) * _ceil_to(w, 16)
 
 

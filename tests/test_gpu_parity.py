@@ -45,9 +45,12 @@ def test_unet_matches_reference_golden(net, dev, golden_dir, n, f, t):
     x = torch.from_numpy(make_input(7, n, f, t)).to(dev)
     with torch.no_grad():
         y, taps = net(x, return_taps=True)
+        y_plain = net(x)            # production path: the last two layers run fused (no up4 tensor is written)
     y = y.cpu().numpy()
     assert y.shape == g["y"].shape
     assert _rel(y, g["y"]) <= TOL
+    assert _rel(y_plain.cpu().numpy(), g["y"]) <= TOL
+    assert _rel(y_plain.cpu().numpy(), y) <= 1e-5          # fused vs unfused tail: summation order only
     for name, tp in taps.items():
         a = tp.cpu().numpy().astype(np.float64).ravel()
         s, sa, sq, cnt = g[f"{name}_stats"]
@@ -691,9 +694,11 @@ def test_split_k_small_batch_path(dev, weights_np, golden_dir, monkeypatch):
         x = torch.from_numpy(make_input(7, n, f, t)).to(dev)
         with torch.no_grad():
             y, taps = m(x, return_taps=True)
+            plain = m(x)
             again = m(x)
         assert _rel(y.cpu().numpy(), g["y"]) <= TOL, (f, t)
-        assert torch.equal(y, again)                                   # fixed summation order: deterministic
+        assert _rel(plain.cpu().numpy(), g["y"]) <= TOL, (f, t)
+        assert torch.equal(plain, again)                               # fixed summation order: deterministic
         for name, tp in taps.items():
             a = tp.cpu().numpy().astype(np.float64).ravel()
             s_, sa, sq, cnt = g[f"{name}_stats"]
