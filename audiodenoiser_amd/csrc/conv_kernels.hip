@@ -279,6 +279,129 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 4) void conv_mfm
 }
 
 // ------------------------------------------------------------------------------------------------
+// LDS-staged epilogue (conv_dma): the accumulator layout of the 32x32 MFMA puts one GEMM column (output channel) per
+// lane, so a direct store writes 4 bytes (fp32) or 2 bytes (fp16) per lane -- 64 store instructions per wave, and the
+// CU's store path retires roughly one wave-instruction per 45 cycles whatever its width.  Here the workgroup's output
+// tile is first assembled in LDS as [pixel][channel] (the two staging images are free after the K loop), then every
+// lane stores 16 contiguous bytes: 8x (fp16) / 4x (fp32) fewer store instructions, whole 128-byte lines per pixel.
+//   phase 1  fp32: ds_write_b32 per accumulator register;  fp16: neighbouring lanes (channels c, c+1) swap one value
+//            of each register pair so that every lane writes a packed pair of halfs (ds_write_b32), bias + ReLU applied
+//   phase 2  lane = (pixel, 16-byte piece): ds_read_b128 -> global store; the 2x2 max-pool reads four pixels' pieces and
+//            reduces them with packed max; the transposed convolution scatters pieces to the four (di, dj) sub-pixels
+// Row stride = BN + 16 bytes of padding (keeps 16-byte alignment, spreads the pixels of a read group over the banks).
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct Piece;
+template <> struct Piece<float> { typedef f32x4 type; };
+template <> struct Piece<_Float16> { typedef f16x8 type; };
+
+template <typename T, int TH, int BN, int WM, int WN, int EPI>
+__device__ __forceinline__ void conv_epilogue_staged(const ConvArgs &p, f32x16 (&acc)[TH * TW / 32 / WM][BN / 32 / WN],
+                                                     const float (&bias_r)[BN / 32 / WN], float *smem, int tid, int lane,
+                                                     int wave, int ct, int n, int ty, int tx)
+{
+    constexpr int MB = TH * TW / 32 / WM, NB = BN / 32 / WN, NT = 64 * WM * WN;
+    constexpr int EPP = 16 / sizeof(T);                    // elements per 16-byte piece
+    constexpr int RS = BN + EPP;                           // row stride of the staging tile, in elements
+    constexpr int NPIX = TH * TW, PPR = BN / EPP;          // pixels of the tile, pieces per pixel
+    typedef typename Piece<T>::type piece_t;
+    const int wm = wave / WN, wn = wave % WN;
+    const int hh = lane >> 5, l31 = lane & 31;
+    T *stage = reinterpret_cast<T *>(smem);
+
+    // ---- phase 1: accumulators (+ bias, ReLU) -> LDS tile [pixel][channel] ----
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int col = (wn * NB + j) * 32 + l31;          // channel inside the tile
+        const float bv = bias_r[j];
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            const int pix0 = (wm * MB + i) * 32 + 4 * hh;  // tile pixel of register r: pix0 + (r&3) + 8*(r>>2)
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                v[r] = acc[i][j][r] + bv;
+                if (EPI != CONVT2X2) v[r] = fmaxf(v[r], 0.f);
+            }
+            if constexpr (sizeof(T) == 4) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) stage[(pix0 + (r & 3) + 8 * (r >> 2)) * RS + col] = v[r];
+            } else {
+                // even lane (channel c): keeps v[r], gets the odd neighbour's v[r]  -> pixel of r,   channels (c, c+1)
+                // odd lane  (channel c): keeps v[r+1], gets the even neighbour's v[r+1] -> pixel of r+1, channels (c-1, c)
+                const bool odd = l31 & 1;
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const float send = odd ? v[r] : v[r + 1];
+                    const float recv = __shfl_xor(send, 1, 64);
+                    const float lo = odd ? recv : v[r], hi = odd ? v[r + 1] : recv;
+                    const int pix = pix0 + ((r + (odd ? 1 : 0)) & 3) + 8 * (r >> 2);
+                    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                    *reinterpret_cast<h2 *>(stage + pix * RS + (col & ~1)) = h2{(_Float16)lo, (_Float16)hi};
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: 16-byte pieces, LDS -> global ----
+    T *outp = static_cast<T *>(p.out);
+    if constexpr (EPI == CONVT2X2) {
+        // GEMM column = (di*2+dj)*Cout + co ; input pixel (gy, gx) -> output pixel (2*gy+di, 2*gx+dj)
+        const int Ho = 2 * p.H, Wo = 2 * p.W;
+#pragma unroll
+        for (int it = 0; it < NPIX * PPR / NT; ++it) {
+            const int id = it * NT + tid;
+            const int pix = id / PPR, part = id - pix * PPR;
+            const int gy = ty * TH + (pix >> 4), gx = tx * TW + (pix & 15);
+            const int col0 = ct * BN + part * EPP;
+            const int ij = col0 / p.Cout, co = col0 - ij * p.Cout;
+            if (gy < p.H && gx < p.W) {
+                const piece_t val = *reinterpret_cast<const piece_t *>(stage + pix * RS + part * EPP);
+                *reinterpret_cast<piece_t *>(outp + (((size_t)n * Ho + 2 * gy + (ij >> 1)) * Wo + 2 * gx + (ij & 1)) * p.Cout + co) = val;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < NPIX * PPR / NT; ++it) {
+            const int id = it * NT + tid;
+            const int pix = id / PPR, part = id - pix * PPR;
+            const int gy = ty * TH + (pix >> 4), gx = tx * TW + (pix & 15);
+            if (gy < p.H && gx < p.W) {
+                const piece_t val = *reinterpret_cast<const piece_t *>(stage + pix * RS + part * EPP);
+                *reinterpret_cast<piece_t *>(outp + (((size_t)n * p.H + gy) * p.W + gx) * p.Cout + ct * BN + part * EPP) = val;
+            }
+        }
+        if constexpr (EPI == CONV3X3_RELU_POOL) {
+            // MaxPool2d(2), floor mode: pooled pixel (py, px) = max over tile pixels (2py..2py+1, 2px..2px+1); values are >= 0
+            const int Hp = p.H >> 1, Wp = p.W >> 1;
+            T *poolp = static_cast<T *>(p.pool);
+            constexpr int NPOOL = NPIX / 4;
+            static_assert(NPOOL * PPR % NT == 0 || NPOOL * PPR < NT, "pool pieces per pass");
+#pragma unroll
+            for (int it = 0; it < (NPOOL * PPR + NT - 1) / NT; ++it) {
+                const int id = it * NT + tid;
+                const int pp = id / PPR, part = id - pp * PPR;
+                const int ly = pp >> 3, lx = pp & 7;                   // pooled position inside the tile (TH/2 x 8)
+                const int py = ((ty * TH) >> 1) + ly, px = ((tx * TW) >> 1) + lx;
+                if (id < NPOOL * PPR && py < Hp && px < Wp) {
+                    const T *b0 = stage + ((2 * ly) * TW + 2 * lx) * RS + part * EPP;
+                    piece_t m = *reinterpret_cast<const piece_t *>(b0);
+                    const piece_t m1 = *reinterpret_cast<const piece_t *>(b0 + RS);
+                    const piece_t m2 = *reinterpret_cast<const piece_t *>(b0 + TW * RS);
+                    const piece_t m3 = *reinterpret_cast<const piece_t *>(b0 + TW * RS + RS);
+#pragma unroll
+                    for (int e = 0; e < EPP; ++e) {
+                        const T a = m[e] > m1[e] ? m[e] : m1[e], b = m2[e] > m3[e] ? m2[e] : m3[e];
+                        m[e] = a > b ? a : b;
+                    }
+                    *reinterpret_cast<piece_t *>(poolp + (((size_t)n * Hp + py) * Wp + px) * p.Cout + ct * BN + part * EPP) = m;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // conv_dma<T>: the same implicit GEMM with LDS-DMA staging (global_load_lds_dwordx4: global -> LDS, no VGPR staging,
 // no ds_write pass) into one of two LDS images while the other is consumed; one barrier per K-chunk.  Used where the
 // register-staged kernel is bound by its copies: the fp16 path (16x faster matrix cores, same CU ingest path; the
@@ -444,7 +567,8 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void conv_dma(const ConvArgs p)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    conv_epilogue<T, TH, BN, WM, WN, EPI>(p, acc, bias_r, lane, wave, ct, n, ty, tx);
+    static_assert((size_t)TH * TW * (BN + 16 / sizeof(T)) * sizeof(T) <= C::LDS_BYTES, "staging tile must fit the two images");
+    conv_epilogue_staged<T, TH, BN, WM, WN, EPI>(p, acc, bias_r, smem, tid, lane, wave, ct, n, ty, tx);
 }
 
 // ------------------------------------------------------------------------------------------------
