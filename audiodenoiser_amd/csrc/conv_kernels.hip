@@ -567,8 +567,14 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void conv_dma(const ConvArgs p)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    static_assert((size_t)TH * TW * (BN + 16 / sizeof(T)) * sizeof(T) <= C::LDS_BYTES, "staging tile must fit the two images");
-    conv_epilogue_staged<T, TH, BN, WM, WN, EPI>(p, acc, bias_r, smem, tid, lane, wave, ct, n, ty, tx);
+    // fp16: LDS-staged 16-byte stores (2-byte stores per lane otherwise).  fp32 (transposed convolutions): direct 4-byte
+    // stores -- staging measured no gain there, and its 66 KB tile would cap the kernel at two workgroups per CU.
+    if constexpr (sizeof(T) == 2) {
+        static_assert((size_t)TH * TW * (BN + 16 / sizeof(T)) * sizeof(T) <= C::LDS_BYTES, "staging tile must fit the two images");
+        conv_epilogue_staged<T, TH, BN, WM, WN, EPI>(p, acc, bias_r, smem, tid, lane, wave, ct, n, ty, tx);
+    } else {
+        conv_epilogue<T, TH, BN, WM, WN, EPI>(p, acc, bias_r, lane, wave, ct, n, ty, tx);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
