@@ -269,6 +269,7 @@ adn::ConvArgs conv_args(const adn_unet *h, const Conv3x3Layer &L, adn::ConvKind 
     a.partial = nullptr;
     a.dotw = nullptr;
     a.dot_out = nullptr;
+    a.dot_bias = 0.f;
     return a;
 }
 
@@ -353,7 +354,7 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
     // ---- up path (model.py:84-91): convT -> (virtual) pad + cat([skip, up]) -> DoubleConv ----
     void *X = tB, *Y = tA;   // X holds the current tensor
     int uh = p.H[4], uw = p.W[4], upc = 1024;
-    bool fused_out = false;
+    bool fused_out = false, fused_in_kernel = false;
     for (int l = 3; l >= 0; --l) {
         const int co = CH[l];
         const ConvTLayer &TL = h->ct[3 - l];
@@ -381,6 +382,7 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
         t.partial = nullptr;
         t.dotw = nullptr;
         t.dot_out = nullptr;
+        t.dot_bias = 0.f;
         ADN_MARK();
         ADN_HIP(adn::launch_conv_mfma(adn::CONVT2X2, t, f16, st));
         // first conv of the DoubleConv reads cat([skip, x1]) virtually
@@ -393,13 +395,20 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
         // The network's last two layers (up4's second conv3x3 and the 1x1 output convolution, model.py:91,93) run fused
         // on the Winograd path: the 64-channel tensor between them is never written (Y holds the two partial planes
         // instead).  Not when block outputs are exported (the up4 tap IS that tensor).
+        // fp16 path: a workgroup of conv_dma holds all 64 channels, the dot is finished in its epilogue (writes y).
+        const bool fuse_f16 = l == 0 && f16 && !taps && b.nct == 1;
         fused_out = l == 0 && h->use_wino && !taps && b.nct == 2;
         if (fused_out) {
             b.dotw = h->dev + h->out_w;
             b.dot_out = static_cast<float *>(Y);
+        } else if (fuse_f16) {
+            b.dotw = h->dev + h->out_w;
+            b.dot_out = y;
+            b.dot_bias = h->out_b;
+            fused_in_kernel = true;
         }
         ADN_MARK();
-        ADN_HIP(launch_conv3(h, fused_out ? adn::CONV3X3_RELU_DOT : adn::CONV3X3_RELU, b, part, st));
+        ADN_HIP(launch_conv3(h, (fused_out || fuse_f16) ? adn::CONV3X3_RELU_DOT : adn::CONV3X3_RELU, b, part, st));
         ++li;
         ADN_HIP(export_tap(5 + (3 - l), Y, co, p.H[l], p.W[l]));
         void *tmp = X;
@@ -411,7 +420,9 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
     }
     // ---- 1x1 output convolution (model.py:93) ----
     ADN_MARK();
-    if (fused_out)      // X = the buffer the fused layer wrote its partial planes to (the loop swapped X and Y)
+    if (fused_in_kernel) {
+        // fp16: y was written by the previous launch; this timing slot stays empty
+    } else if (fused_out)      // X = the buffer the fused layer wrote its partial planes to (the loop swapped X and Y)
         ADN_HIP(adn::launch_dot_finish(static_cast<const float *>(X), 2, h->out_b, y, (long)N * F * T, st));
     else
         ADN_HIP(adn::launch_conv_out(X, f16, h->dev + h->out_w, h->out_b, y, (long)N * F * T, st));

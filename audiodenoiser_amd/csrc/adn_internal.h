@@ -38,6 +38,7 @@ struct ConvArgs {
     // CONV3X3_RELU_DOT: weights of the fused 1x1 convolution (Cout floats) and its partial planes [nct][N][H][W]
     const float *dotw;
     float *dot_out;
+    float dot_bias;        // fp16 kernel only (one workgroup holds all 64 channels: dot_out IS the network output)
 };
 
 // Number of K splits for a 3x3 layer launched as `nwg` Winograd workgroups of `nchunk` chunks: only when the grid
@@ -53,6 +54,7 @@ inline int wino_ksplit(long nwg, int nchunk)
 // workgroup contracts its 32 output channels with the weights of the following 1x1 convolution (reference model.py:68,93,
 // the network's last layer) and stores one float per pixel into plane `ct` of ConvArgs::dot_out; launch_dot_finish adds
 // the planes and the bias.  Saves the 64-channel tensor's HBM round trip (write + read of N*H*W*64 floats).
+// fp16 kernel (conv_dma, 64 couts per workgroup): the dot is complete inside the workgroup, dot_out is the final output.
 enum ConvKind { CONV3X3_RELU = 0, CONV3X3_RELU_POOL = 1, CONVT2X2 = 2, CONV3X3_RELU_DOT = 3 };
 
 // Tile geometry chosen per layer (must match the weight packing).

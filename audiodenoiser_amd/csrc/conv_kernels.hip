@@ -360,6 +360,27 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs &p, f32x16 (
                 *reinterpret_cast<piece_t *>(outp + (((size_t)n * Ho + 2 * gy + (ij >> 1)) * Wo + 2 * gx + (ij & 1)) * p.Cout + co) = val;
             }
         }
+    } else if constexpr (EPI == CONV3X3_RELU_DOT) {
+        // Fused last layer (model.py:91,93): the workgroup holds all BN = Cout channels of its pixels, so the 1x1
+        // convolution is finished here: each lane dots its 16-byte piece with the matching weights, the PPR lanes of a
+        // pixel add up with xor-shuffles (fixed order), lane 0 of the pixel writes the fp32 network output.
+        static_assert(PPR <= 64 && (PPR & (PPR - 1)) == 0 && NT % PPR == 0, "pieces of a pixel must sit in one wave");
+        float wv[EPP];
+#pragma unroll
+        for (int e = 0; e < EPP; ++e) wv[e] = p.dotw[(tid % PPR) * EPP + e];
+#pragma unroll
+        for (int it = 0; it < NPIX * PPR / NT; ++it) {
+            const int id = it * NT + tid;
+            const int pix = id / PPR, part = id - pix * PPR;
+            const int gy = ty * TH + (pix >> 4), gx = tx * TW + (pix & 15);
+            const piece_t val = *reinterpret_cast<const piece_t *>(stage + pix * RS + part * EPP);
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < EPP; ++e) s += wv[e] * (float)val[e];
+#pragma unroll
+            for (int o = PPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            if (part == 0 && gy < p.H && gx < p.W) p.dot_out[((size_t)n * p.H + gy) * p.W + gx] = s + p.dot_bias;
+        }
     } else {
 #pragma unroll
         for (int it = 0; it < NPIX * PPR / NT; ++it) {
@@ -766,12 +787,18 @@ hipError_t launch_conv_mfma_t(ConvKind kind, const ConvArgs &a, hipStream_t st)
             return launch_dma_cfg<T, 8, 128, 2, 2, 1, 4, CONVT2X2, 2>(a, st);
         }
         if (staging_regs()) {
+            if (kind == CONV3X3_RELU_DOT) return hipErrorInvalidValue;
             if (kind == CONV3X3_RELU_POOL) return launch_cfg<T, 32, 64, 8, 1, 9, 1, CONV3X3_RELU_POOL>(a, st);
             return launch_cfg<T, 32, 64, 8, 1, 9, 1, CONV3X3_RELU>(a, st);
+        }
+        if (kind == CONV3X3_RELU_DOT) {
+            if (a.nct != 1 || !a.dotw || !a.dot_out) return hipErrorInvalidValue;      // needs all couts in one workgroup
+            return launch_dma_cfg<T, 32, 64, 8, 1, 9, 1, CONV3X3_RELU_DOT, 4>(a, st);
         }
         if (kind == CONV3X3_RELU_POOL) return launch_dma_cfg<T, 32, 64, 8, 1, 9, 1, CONV3X3_RELU_POOL, 4>(a, st);
         return launch_dma_cfg<T, 32, 64, 8, 1, 9, 1, CONV3X3_RELU, 4>(a, st);
     } else {
+        if (kind == CONV3X3_RELU_DOT) return hipErrorInvalidValue;     // fp32: only the Winograd kernel fuses the last layer
         if (kind == CONVT2X2) {
             if (staging_regs()) return launch_cfg<T, 8, 128, 2, 2, 1, 4, CONVT2X2>(a, st);
             return launch_dma_cfg<T, 8, 128, 2, 2, 1, 4, CONVT2X2, 2>(a, st);
