@@ -229,6 +229,7 @@ def bench_stft(dev, clips=10000, length=132300, n_fft=1024, hop=256, steps=20, w
                         "algorithmic_bytes_per_launch": clips * bytes_per_clip, "bytes_per_clip": bytes_per_clip}}
     if cpu_clips > 0:
         import oracle
+        oracle.set_num_threads(host_cores())                   # the CPU share this process really has
         host = a[:cpu_clips].cpu().numpy()
         oracle.stft_mag(host[:2], n_fft, hop, True)
         t0 = time.perf_counter()

@@ -62,6 +62,7 @@ def lib() -> ctypes.CDLL:
         L.adno_stft_mag.argtypes = [fp, ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, fp]
         L.adno_quantize_pad.argtypes = [fp, ctypes.c_int, ctypes.c_int, fp, ctypes.c_int, ctypes.c_int]
         L.adno_num_threads.restype = ctypes.c_int
+        L.adno_set_num_threads.argtypes = [ctypes.c_int]
         _lib = L
     return _lib
 
@@ -151,3 +152,8 @@ def quantize_pad(spec: np.ndarray, target_size) -> np.ndarray:
 
 def num_threads() -> int:
     return int(lib().adno_num_threads())
+
+
+def set_num_threads(n: int) -> None:
+    """Cap the OpenMP team of the C restatement (the timed CPU baseline uses the process's CPU share)."""
+    lib().adno_set_num_threads(int(n))

@@ -417,3 +417,14 @@ int adno_num_threads(void)
     return 1;
 #endif
 }
+
+/* cap the OpenMP team (bench.py sets it to the process's CPU share: a cgroup-limited box exposes every core in the
+ * affinity mask, and 128 threads on 16 cores' worth of quota only add scheduling noise) */
+void adno_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n >= 1) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
