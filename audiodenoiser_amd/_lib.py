@@ -50,6 +50,7 @@ def load() -> ctypes.CDLL:
         L.adn_unet_get_timing.argtypes = [vp, ci, c_float_p]
         L.adn_stft_n_frames.argtypes = [cl, ci, ci, ci, ctypes.POINTER(cl)]
         L.adn_stft_mag.argtypes = [vp, ci, cl, ci, ci, ci, vp, vp]
+        L.adn_stft_mag_fit.argtypes = [vp, ci, cl, ci, ci, ci, vp, ci, ci, vp]
         L.adn_quantize_pad.argtypes = [vp, ci, ci, ci, vp, ci, ci, vp]
         L.adn_per_clip_l1.argtypes = [vp, vp, ci, cl, vp, vp]
         L.adn_perceptual_loss_workspace_bytes.argtypes = [ci, ci, ci, ctypes.POINTER(sz)]
@@ -62,7 +63,7 @@ def load() -> ctypes.CDLL:
         L.adn_istft.argtypes = [vp, ci, ci, ci, ci, vp, sz, vp, vp]
         for name in ("adn_device_count", "adn_unet_create", "adn_unet_create_ex", "adn_unet_destroy", "adn_unet_workspace_bytes",
                      "adn_unet_forward", "adn_unet_forward_taps", "adn_unet_set_timing", "adn_unet_get_timing",
-                     "adn_stft_n_frames", "adn_stft_mag", "adn_quantize_pad", "adn_per_clip_l1",
+                     "adn_stft_n_frames", "adn_stft_mag", "adn_stft_mag_fit", "adn_quantize_pad", "adn_per_clip_l1",
                      "adn_perceptual_loss_workspace_bytes", "adn_perceptual_loss", "adn_istft_length",
                      "adn_griffin_lim_workspace_bytes", "adn_griffin_lim", "adn_stft_complex",
                      "adn_istft_workspace_bytes", "adn_istft"):
@@ -91,7 +92,7 @@ def check(rc: int, what: str) -> None:
 EXPORTED_SYMBOLS = (
     "adn_version", "adn_last_error", "adn_device_count", "adn_unet_create", "adn_unet_create_ex", "adn_unet_destroy",
     "adn_unet_workspace_bytes", "adn_unet_forward", "adn_unet_forward_taps", "adn_unet_set_timing",
-    "adn_unet_get_timing", "adn_stft_n_frames", "adn_stft_mag",
+    "adn_unet_get_timing", "adn_stft_n_frames", "adn_stft_mag", "adn_stft_mag_fit",
     "adn_quantize_pad", "adn_per_clip_l1", "adn_perceptual_loss_workspace_bytes", "adn_perceptual_loss",
     "adn_istft_length", "adn_griffin_lim_workspace_bytes", "adn_griffin_lim", "adn_stft_complex",
     "adn_istft_workspace_bytes", "adn_istft",

@@ -656,9 +656,33 @@ int adn_stft_mag(const float *audio, int n_clips, long length, int n_fft, int ho
     long nfr = 0;
     adn_stft_n_frames(length, n_fft, hop, center, &nfr);
     if (nfr <= 0) return fail(ADN_ERR_INVALID, "adn_stft_mag: audio shorter than n_fft");
-    hipError_t e = adn::launch_stft_mag(audio, n_clips, length, n_fft, hop, center, nfr, out,
+    const int nb = n_fft / 2 + 1;
+    hipError_t e = adn::launch_stft_mag(audio, n_clips, length, n_fft, hop, center, nfr, out, nb, nfr, (long)nb * nfr, 0,
                                         static_cast<hipStream_t>(stream));
     if (e == hipErrorInvalidValue) return fail(ADN_ERR_INVALID, "adn_stft_mag: hop too large for on-chip staging or grid too large");
+    if (e != hipSuccess) return fail_hip(e, "stft launch");
+    return ADN_OK;
+}
+
+int adn_stft_mag_fit(const float *audio, int n_clips, long length, int n_fft, int hop, int center, float *out, int H, int W,
+                     void *stream)
+{
+    if (!audio || !out) return fail(ADN_ERR_INVALID, "adn_stft_mag_fit: null pointer");
+    if (n_clips < 1 || hop < 1 || H < 1 || W < 1) return fail(ADN_ERR_INVALID, "adn_stft_mag_fit: n_clips, hop, H, W must be >= 1");
+    if (n_fft < 64 || n_fft > 4096 || (n_fft & (n_fft - 1)))
+        return fail(ADN_ERR_INVALID, "adn_stft_mag_fit: n_fft must be a power of two in [64, 4096]");
+    if (length >= (1L << 30) || hop > (1 << 20) || (long)H * W >= (1L << 30))
+        return fail(ADN_ERR_INVALID, "adn_stft_mag_fit: clip length and H*W must be < 2^30, hop <= 2^20");
+    long nfr = 0;
+    adn_stft_n_frames(length, n_fft, hop, center, &nfr);
+    if (nfr <= 0) return fail(ADN_ERR_INVALID, "adn_stft_mag_fit: audio shorter than n_fft");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nb = n_fft / 2 + 1;
+    // zero padding at the bottom / right of the window (data_loader.py:59-70) where the spectrogram is smaller than it
+    if (W > nfr || H > nb) ADN_HIP(hipMemsetAsync(out, 0, (size_t)n_clips * H * W * sizeof(float), st));
+    const long nfc = nfr < W ? nfr : W;                   // frames that fall inside the window: the only ones computed
+    hipError_t e = adn::launch_stft_mag(audio, n_clips, length, n_fft, hop, center, nfc, out, nb < H ? nb : H, W, (long)H * W, 1, st);
+    if (e == hipErrorInvalidValue) return fail(ADN_ERR_INVALID, "adn_stft_mag_fit: hop too large for on-chip staging or grid too large");
     if (e != hipSuccess) return fail_hip(e, "stft launch");
     return ADN_OK;
 }

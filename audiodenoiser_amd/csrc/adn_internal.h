@@ -82,8 +82,8 @@ hipError_t launch_conv_out(const void *in, bool f16, const float *w64, float bia
 // NHWC -> NCHW fp32 (parity-test export only).
 hipError_t launch_nhwc_to_nchw(const void *in, bool f16, float *out, int N, int H, int W, int C, hipStream_t st);
 
-hipError_t launch_stft_mag(const float *audio, int n_clips, long L, int n_fft, int hop, int center,
-                           long n_frames, float *out, hipStream_t st);
+hipError_t launch_stft_mag(const float *audio, int n_clips, long L, int n_fft, int hop, int center, long n_frames,
+                           float *out, int rows, long row_stride, long clip_stride, int quantize, hipStream_t st);
 hipError_t stft_tables(int n_fft, const float **out);
 // Griffin-Lim building blocks (gl_kernels.hip); complex spectrograms are frame-major [clip][frame][F] float2
 hipError_t launch_gl_polar(const float *mag, const float *rnd, int n_clips, int F, int T, void *spec, hipStream_t st);

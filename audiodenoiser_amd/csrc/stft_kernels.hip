@@ -17,6 +17,8 @@
 #include "adn_internal.h"
 #include "fft_core.h"
 
+#include <hip/hip_fp16.h>
+
 #include <cmath>
 #include <cstdlib>
 #include <map>
@@ -27,6 +29,21 @@ namespace adn {
 namespace {
 
 using namespace fftcore;
+
+// Where and how the magnitudes are stored.  Plain STFT: rows = n_fft/2+1, row_stride = n_frames, clip_stride = rows *
+// n_frames, quantize = 0.  Fused loader rule (adn_stft_mag_fit): the (H, W) window of SpectrogramDataset's
+// _pad_or_truncate (data_loader.py:54-72) -- only rows < H and frames < W are computed / stored, at row stride W --
+// and every value goes through the fp16 round trip of data_loader.py:41-42.
+struct StftOut {
+    long row_stride, clip_stride;
+    int rows;
+    int quantize;
+};
+
+__device__ __forceinline__ float stft_emit(float v, int quantize)
+{
+    return quantize ? __half2float(__float2half_rn(v)) : v;
+}
 
 template <int M>
 struct StftCfg {
@@ -45,7 +62,7 @@ template <int M>
 __global__ __launch_bounds__(STFT_THREADS) void stft_mag_kernel(const float *__restrict__ audio, long L, int hop, int pad,
                                                                long n_frames, int groups_per_clip,
                                                                const float *__restrict__ tables, float *__restrict__ out,
-                                                               int work_floats)
+                                                               int work_floats, const StftOut o)
 {
     using C = StftCfg<M>;
     constexpr int N = C::N, TPF = C::TPF, FPB = C::FPB, FB = C::FB, NBATCH = C::NBATCH, MAGSTR = C::MAGSTR;
@@ -125,10 +142,10 @@ __global__ __launch_bounds__(STFT_THREADS) void stft_mag_kernel(const float *__r
     }
 
     // ---- store: lanes run along the frame axis ----
-    float *ob = out + clip * (long)(M + 1) * n_frames;
+    float *ob = out + clip * o.clip_stride;
     for (int idx = tid; idx < (M + 1) * FPB; idx += STFT_THREADS) {
         const int k = idx / FPB, f = idx - k * FPB;
-        if (f0 + f < n_frames) ob[(long)k * n_frames + f0 + f] = s_mag[k * MAGSTR + f];
+        if (f0 + f < n_frames && k < o.rows) ob[(long)k * o.row_stride + f0 + f] = stft_emit(s_mag[k * MAGSTR + f], o.quantize);
     }
 }
 
@@ -286,7 +303,7 @@ template <int M, int NW, int FPB, int WPE>
 __global__ __launch_bounds__(NW * 64, WPE) void stft_wave_kernel(const float *__restrict__ audio, long L, int hop, int pad,
                                                              long n_frames, int groups_per_clip, int gpb,
                                                              int blocks_per_clip, const float *__restrict__ tables,
-                                                             float *__restrict__ out, int ablate_arg)
+                                                             float *__restrict__ out, int ablate_arg, const StftOut o)
 {
 #ifdef ADN_EXPERIMENTS
     const int ablate = ablate_arg;              // timing experiments (ADN_STFT_ABLATE): skip loads (1) / stores (2)
@@ -314,7 +331,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void stft_wave_kernel(const float *__
     const int g_first = (lid - clip * blocks_per_clip) * gpb;
     const int g_end = min(g_first + gpb, groups_per_clip);
     const float *aud = audio + (long)clip * L;
-    float *oclip = out + (long)clip * (M + 1) * n_frames;
+    float *oclip = out + (long)clip * o.clip_stride;
     v2f *sc = s_sc + slot * SCSZ;
 
     const int Li = (int)L;                                // adn_stft_mag guarantees L < 2^30
@@ -447,7 +464,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void stft_wave_kernel(const float *__
             if constexpr (FPB == 16 && ROWS >= 2 && ROWS <= 32) {
                 constexpr int HALF = ROWS / 2, SUB = 16 / HALF, NBLK = (M + 1 + 31) / 32;
                 const int krow0 = (rid >> 1) + 16 * (rid & 1);
-                const unsigned voff = (unsigned)krow0 * (unsigned)n_frames + (unsigned)fr;
+                const unsigned voff = (unsigned)krow0 * (unsigned)o.row_stride + (unsigned)fr;
                 const float *mp0 = s_mag + krow0 * MAGSTR + fr;
                 if (fglob < n_frames) {
 #pragma unroll
@@ -456,18 +473,19 @@ __global__ __launch_bounds__(NW * 64, WPE) void stft_wave_kernel(const float *__
                         for (int j = 0; j < SUB; ++j) {
                             const int kk = 32 * blk + HALF * j;         // compile-time part of the row index
                             if ((ablate & 2) && kk > 0) break;          // timing experiment: one row block only
-                            if (kk + 31 <= M || kk + krow0 <= M)
-                                (gbase + (long)kk * n_frames)[voff] = mp0[kk * MAGSTR];
+                            if ((kk + 31 <= M || kk + krow0 <= M) && kk + krow0 < o.rows)
+                                (gbase + (long)kk * o.row_stride)[voff] = stft_emit(mp0[kk * MAGSTR], o.quantize);
                         }
                 }
             } else {
                 if (fglob < n_frames && !((ablate & 2) && rid > 0)) {
-                    float *op = oclip + (long)rid * n_frames + fglob;
+                    float *op = oclip + (long)rid * o.row_stride + fglob;
                     const float *mp = s_mag + rid * MAGSTR + fr;
-                    const long ostep = (long)ROWS * n_frames;
+                    const long ostep = (long)ROWS * o.row_stride;
+                    const int kend = M + 1 < o.rows ? M + 1 : o.rows;
 #pragma unroll 4
-                    for (int k = rid; k < ((ablate & 2) ? 1 : M + 1); k += ROWS) {
-                        *op = *mp;
+                    for (int k = rid; k < ((ablate & 2) ? 1 : kend); k += ROWS) {
+                        *op = stft_emit(*mp, o.quantize);
                         op += ostep;
                         mp += ROWS * MAGSTR;
                     }
@@ -492,7 +510,7 @@ inline int stft_ablate()
 
 template <int M, int NW, int FPB, int WPE = 3>
 hipError_t launch_wave(const float *audio, int n_clips, long L, int hop, int pad, long n_frames, const float *tables,
-                       float *out, hipStream_t st, int gpb)
+                       float *out, const StftOut &o, hipStream_t st, int gpb)
 {
     constexpr int TPF = M / 8, SLOTS = NW * 64 / TPF;
     const long groups = (n_frames + FPB - 1) / FPB;
@@ -509,7 +527,7 @@ hipError_t launch_wave(const float *audio, int n_clips, long L, int hop, int pad
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(NW * 64), lds, st, audio, L, hop, pad, n_frames, (int)groups,
-                       gpb, (int)bpc, tables, out, stft_ablate());
+                       gpb, (int)bpc, tables, out, stft_ablate(), o);
     return hipGetLastError();
 }
 
@@ -552,7 +570,7 @@ hipError_t get_tables(int n_fft, const float **out)
 
 template <int M>
 hipError_t launch_m(const float *audio, int n_clips, long L, int hop, int pad, long n_frames, const float *tables,
-                    float *out, hipStream_t st)
+                    float *out, const StftOut &o, hipStream_t st)
 {
     using C = StftCfg<M>;
     const long groups = (n_frames + C::FPB - 1) / C::FPB;
@@ -571,7 +589,7 @@ hipError_t launch_m(const float *audio, int n_clips, long L, int hop, int pad, l
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(STFT_THREADS), lds, st, audio, L, hop, pad, n_frames,
-                       (int)groups, tables, out, (int)work);
+                       (int)groups, tables, out, (int)work, o);
     return hipGetLastError();
 }
 
@@ -581,9 +599,12 @@ hipError_t launch_m(const float *audio, int n_clips, long L, int hop, int pad, l
 // tw2[M/2+1] = exp(-2 pi i k / N); shared with the inverse-STFT kernels
 hipError_t stft_tables(int n_fft, const float **out) { return get_tables(n_fft, out); }
 
+// n_frames = frames to compute per clip (all of them, or only those inside the fitted window); rows / row_stride /
+// clip_stride / quantize: see StftOut
 hipError_t launch_stft_mag(const float *audio, int n_clips, long L, int n_fft, int hop, int center, long n_frames,
-                           float *out, hipStream_t st)
+                           float *out, int rows, long row_stride, long clip_stride, int quantize, hipStream_t st)
 {
+    const StftOut o{row_stride, clip_stride, rows, quantize};
     const float *tables = nullptr;
     hipError_t e = get_tables(n_fft, &tables);
     if (e != hipSuccess) return e;
@@ -600,37 +621,37 @@ hipError_t launch_stft_mag(const float *audio, int n_clips, long L, int n_fft, i
 #endif
     if (variant != 0) {
         switch (n_fft) {
-            case 64: return launch_wave<32, 1, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
-            case 128: return launch_wave<64, 2, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
-            case 256: return launch_wave<128, 4, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
+            case 64: return launch_wave<32, 1, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st, gpb);
+            case 128: return launch_wave<64, 2, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st, gpb);
+            case 256: return launch_wave<128, 4, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st, gpb);
             case 512:
 #ifdef ADN_EXPERIMENTS
-                if (variant == 1) return launch_wave<256, 8, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
-                if (variant == 2) return launch_wave<256, 4, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
-                if (variant == 3) return launch_wave<256, 2, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
-                if (variant == 4) return launch_wave<256, 2, 32>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
+                if (variant == 1) return launch_wave<256, 8, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st, gpb);
+                if (variant == 2) return launch_wave<256, 4, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st, gpb);
+                if (variant == 3) return launch_wave<256, 2, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st, gpb);
+                if (variant == 4) return launch_wave<256, 2, 32>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st, gpb);
 #endif
                 // measured on 10 k x 3 s clips (ms): <8,16> 9.31, <4,16> 5.42, <2,32> 6.08, <2,16> 4.78, <4,32> 4.71
-                return launch_wave<256, 4, 32>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
+                return launch_wave<256, 4, 32>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st, gpb);
             case 1024:
 #ifdef ADN_EXPERIMENTS
-                if (variant == 1) return launch_wave<512, 8, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
-                if (variant == 3) return launch_wave<512, 8, 32>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
-                if (variant == 4) return launch_wave<512, 4, 32>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
-                if (variant == 5) return launch_wave<512, 8, 16, 4>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
+                if (variant == 1) return launch_wave<512, 8, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st, gpb);
+                if (variant == 3) return launch_wave<512, 8, 32>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st, gpb);
+                if (variant == 4) return launch_wave<512, 4, 32>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st, gpb);
+                if (variant == 5) return launch_wave<512, 8, 16, 4>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st, gpb);
 #endif
-                return launch_wave<512, 4, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, st, gpb);
+                return launch_wave<512, 4, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st, gpb);
             default: break;
         }
     }
     switch (n_fft) {
-        case 64: return launch_m<32>(audio, n_clips, L, hop, pad, n_frames, tables, out, st);
-        case 128: return launch_m<64>(audio, n_clips, L, hop, pad, n_frames, tables, out, st);
-        case 256: return launch_m<128>(audio, n_clips, L, hop, pad, n_frames, tables, out, st);
-        case 512: return launch_m<256>(audio, n_clips, L, hop, pad, n_frames, tables, out, st);
-        case 1024: return launch_m<512>(audio, n_clips, L, hop, pad, n_frames, tables, out, st);
-        case 2048: return launch_m<1024>(audio, n_clips, L, hop, pad, n_frames, tables, out, st);
-        case 4096: return launch_m<2048>(audio, n_clips, L, hop, pad, n_frames, tables, out, st);
+        case 64: return launch_m<32>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st);
+        case 128: return launch_m<64>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st);
+        case 256: return launch_m<128>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st);
+        case 512: return launch_m<256>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st);
+        case 1024: return launch_m<512>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st);
+        case 2048: return launch_m<1024>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st);
+        case 4096: return launch_m<2048>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st);
         default: return hipErrorInvalidValue;
     }
 }

@@ -139,10 +139,11 @@ class WavToSpecDataset(Dataset):
 
     def _spec_batch(self, audios):
         """(B, L) float32 audio (array, list of equally long arrays, or tensor) -> (B, 1, H, W) float32 on the device."""
-        from .stft import stft_magnitude
+        from .stft import stft_magnitude_fit
         a = audios if isinstance(audios, torch.Tensor) else torch.from_numpy(np.stack(audios))
         a = a.to(self.device, non_blocking=True)
-        return quantize_pad_on_device(stft_magnitude(a, self.n_fft, self.hop_length, True), self.target_size)
+        # STFT + fp16 round trip + crop/pad in ONE kernel: only the frames inside target_size are computed
+        return stft_magnitude_fit(a, self.target_size, self.n_fft, self.hop_length, True)
 
     def __getitem__(self, idx):
         if torch.utils.data.get_worker_info() is not None:

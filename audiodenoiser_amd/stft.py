@@ -49,6 +49,27 @@ def stft_magnitude(audio: torch.Tensor, n_fft: int = N_FFT, hop_length: int = HO
     return out[0] if single else out
 
 
+def stft_magnitude_fit(audio: torch.Tensor, target_size, n_fft: int = N_FFT, hop_length: int = HOP_LENGTH,
+                       center: bool = True) -> torch.Tensor:
+    """``audio`` (n_clips, L) float32 on a ROCm device -> (n_clips, 1, H, W): the STFT magnitude with the loader rule of
+    ``SpectrogramDataset`` (fp16 round trip, crop / bottom-right zero pad to ``target_size``; reference
+    ``data_loader.py:41-42,54-72``) applied in the same kernel.  Equal, bit for bit, to
+    ``quantize_pad_on_device(stft_magnitude(audio, ...), target_size)`` but computes only the frames inside the window."""
+    if not audio.is_cuda or audio.dtype != torch.float32 or audio.dim() != 2:
+        raise ValueError("stft_magnitude_fit: expected a (n_clips, L) float32 tensor on a ROCm device")
+    a = audio.contiguous()
+    n_clips, length = a.shape
+    H, W = (int(v) for v in target_size)
+    if stft_n_frames(length, n_fft, hop_length, center) <= 0:
+        raise ValueError(f"audio of {length} samples is shorter than n_fft={n_fft}")
+    out = torch.empty((n_clips, 1, H, W), dtype=torch.float32, device=a.device)
+    stream = torch.cuda.current_stream(a.device).cuda_stream
+    with torch.cuda.device(a.device):
+        _lib.check(_lib.load().adn_stft_mag_fit(a.data_ptr(), n_clips, length, n_fft, hop_length, 1 if center else 0,
+                                                out.data_ptr(), H, W, stream), "adn_stft_mag_fit")
+    return out
+
+
 def _dispatch(audio, n_fft, hop_length, center, device):
     if isinstance(audio, torch.Tensor):
         return stft_magnitude(audio, n_fft, hop_length, center)

@@ -227,6 +227,29 @@ def bench_stft(dev, clips=10000, length=132300, n_fft=1024, hop=256, steps=20, w
                         "frac": round(gbs / 8000.0, 4), "traffic": traffic, "traffic_source": source,
                         "kernel": "stft_wave_kernel<512,4,16,3>, 1 launch per step",
                         "algorithmic_bytes_per_launch": clips * bytes_per_clip, "bytes_per_clip": bytes_per_clip}}
+    # the same clips straight to the network's input format (wav -> forward flow, BASELINE configs[0] at scale): STFT +
+    # fp16 round trip + crop to 513x256 in one kernel (adn_stft_mag_fit) -- only the 256 frames the network reads
+    fit = torch.empty((clips, 1, F_BINS, T_FRAMES), dtype=torch.float32, device=dev)
+
+    def run_fit():
+        _lib.check(L.adn_stft_mag_fit(a.data_ptr(), clips, length, n_fft, hop, 1, fit.data_ptr(), F_BINS, T_FRAMES, st),
+                   "adn_stft_mag_fit")
+    for _ in range(warmup):
+        run_fit()
+    torch.cuda.synchronize(dev)
+    e0.record()
+    for _ in range(steps):
+        run_fit()
+    e1.record()
+    torch.cuda.synchronize(dev)
+    ms_fit = e0.elapsed_time(e1) / steps
+    fit_bytes = clips * ((T_FRAMES - 1) * hop + n_fft // 2 + F_BINS * T_FRAMES) * 4       # samples the 256 frames touch + output
+    res["fused_to_network_input"] = {
+        "what": f"adn_stft_mag_fit: the same clips -> ({clips},1,{F_BINS},{T_FRAMES}) = STFT + fp16 round trip + crop "
+                "(data_loader.py:41-42,54-72) in one kernel, bit-identical to adn_stft_mag + adn_quantize_pad",
+        "ms_per_launch": round(ms_fit, 4), "clips_per_s": round(clips / (ms_fit * 1e-3), 1),
+        "algorithmic_GBps": round(fit_bytes / (ms_fit * 1e-3) / 1e9, 1)}
+    del fit
     if cpu_clips > 0:
         import oracle
         oracle.set_num_threads(host_cores())                   # the CPU share this process really has

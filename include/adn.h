@@ -100,6 +100,14 @@ int adn_stft_n_frames(long length, int n_fft, int hop, int center, long *n_frame
 int adn_stft_mag(const float *audio, int n_clips, long length, int n_fft, int hop, int center,
                  float *out, void *stream);
 
+/* STFT magnitude fused with the loader rule that follows it on the wav -> network path: out (n_clips, H, W) =
+ * fp32(fp16(|STFT|)) cropped / zero padded at the bottom and right to (H, W), i.e. adn_quantize_pad(adn_stft_mag(...))
+ * (code/data_loader.py:41-42,54-72 applied to code/create_test_dataset.py:35-41) in one kernel: only the min(n_frames, W)
+ * frames inside the window are computed, nothing is written outside it, rows are W floats apart.  Bit-identical to the
+ * two-step form. */
+int adn_stft_mag_fit(const float *audio, int n_clips, long length, int n_fft, int hop, int center,
+                     float *out, int H, int W, void *stream);
+
 /* Loader arithmetic: replaces SpectrogramDataset.__getitem__/_pad_or_truncate (code/data_loader.py:41-42,
  * 54-72) for a batch already on the device: out(n,H,W) = fp32(fp16(in(n,h,w))) cropped / zero padded at the
  * bottom and right. */

@@ -42,6 +42,12 @@ def test_host_only_entry_points_and_errors():
         assert L.adn_stft_n_frames(length, n_fft, hop, center, ctypes.byref(nfr)) == 0
         assert nfr.value == expect
     assert L.adn_stft_mag(None, 1, 1000, 512, 128, 0, None, None) == 1
+    buf = (ctypes.c_float * 16)()
+    pbuf = ctypes.cast(buf, ctypes.c_void_p)
+    assert L.adn_stft_mag_fit(None, 1, 1000, 512, 128, 1, None, 256, 64, None) == 1
+    assert L.adn_stft_mag_fit(pbuf, 1, 1000, 500, 128, 1, pbuf, 256, 64, None) == 1        # n_fft not a power of two
+    assert L.adn_stft_mag_fit(pbuf, 1, 100, 512, 128, 0, pbuf, 256, 64, None) == 1         # shorter than n_fft
+    assert L.adn_stft_mag_fit(pbuf, 1, 1000, 512, 128, 1, pbuf, 0, 64, None) == 1
     assert L.adn_unet_forward(None, None, None, 1, 16, 16, None, 0, None) == 1
 
 
