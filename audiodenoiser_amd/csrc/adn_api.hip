@@ -270,6 +270,8 @@ adn::ConvArgs conv_args(const adn_unet *h, const Conv3x3Layer &L, adn::ConvKind 
     a.dotw = nullptr;
     a.dot_out = nullptr;
     a.dot_bias = 0.f;
+    a.firstw = nullptr;
+    a.firstb = nullptr;
     return a;
 }
 
@@ -316,8 +318,20 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
     };
 
     // ---- down path (model.py:72-79) ----
+    // Winograd path: the first convolution (Cin = 1) is fused into down1's second one -- its 64-channel result is computed
+    // tile by tile inside that kernel and never written (timing slot 0 stays empty).
+    bool fused_first = h->use_wino;
+    if (fused_first && h->allow_split) {
+        // split-K (opt-in, small batches) may cut down1's second conv along K: the fused form has no split variant
+        adn::ConvArgs probe{};
+        probe.N = N; probe.H = p.H[0]; probe.W = p.W[0];
+        probe.tilesY = (p.H[0] + 15) / 16;
+        probe.nct = 64 / h->wino_bn;
+        if (adn::wino_ksplit(adn::wino_workgroups(probe), 64 / 8) > 1) fused_first = false;
+    }
     ADN_MARK();
-    ADN_HIP(adn::launch_conv_first(x, h->dev + h->first_w, h->dev + h->first_b, tA, f16, N, p.H[0], p.W[0], st));
+    if (!fused_first)
+        ADN_HIP(adn::launch_conv_first(x, h->dev + h->first_w, h->dev + h->first_b, tA, f16, N, p.H[0], p.W[0], st));
     int li = 0;
     const void *cur = tA;
     for (int l = 0; l < 4; ++l) {
@@ -332,6 +346,11 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
         }
         adn::ConvArgs a = conv_args(h, h->c3[li], adn::CONV3X3_RELU_POOL, cur, CH[l], nullptr, 0, 0, 0, skip, pool, N,
                                     p.H[l], p.W[l]);
+        if (l == 0 && fused_first) {
+            a.s0 = adn::ConvSrc{x, p.H[0], p.W[0], 1, 0, 0};        // the network input; the 64 channels are computed on the fly
+            a.firstw = h->dev + h->first_w;
+            a.firstb = h->dev + h->first_b;
+        }
         ADN_MARK();
         ADN_HIP(launch_conv3(h, adn::CONV3X3_RELU_POOL, a, part, st));
         ++li;
@@ -383,6 +402,8 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
         t.dotw = nullptr;
         t.dot_out = nullptr;
         t.dot_bias = 0.f;
+        t.firstw = nullptr;
+        t.firstb = nullptr;
         ADN_MARK();
         ADN_HIP(adn::launch_conv_mfma(adn::CONVT2X2, t, f16, st));
         // first conv of the DoubleConv reads cat([skip, x1]) virtually

@@ -39,6 +39,10 @@ struct ConvArgs {
     const float *dotw;
     float *dot_out;
     float dot_bias;        // fp16 kernel only (one workgroup holds all 64 channels: dot_out IS the network output)
+    // Fused first layer (Winograd kernel, down1's second conv): s0.ptr is the network INPUT (N,1,H,W) and the halo of the
+    // 64-channel tensor Conv2d(1->64)+BN+ReLU (model.py:11-13 via :56) is computed on the fly from firstw [9 taps][64] and
+    // firstb [64] (BatchNorm folded) instead of being copied; nullptr = ordinary NHWC source
+    const float *firstw, *firstb;
 };
 
 // Number of K splits for a 3x3 layer launched as `nwg` Winograd workgroups of `nchunk` chunks: only when the grid

@@ -89,9 +89,16 @@ struct DmaGeom {
 
 // SPLIT = 1: split-K launch for small batches (see ConvArgs::ksplit): the workgroup sums chunks [c0, c0 + nchunk/ksplit)
 // and stores raw partial sums; wino_reduce_kernel finishes the layer.
-template <int EPI, int NW, int SPLIT>
+// SRC = 1: the source is the 1-channel network input and the halo of Conv2d(1->64)+BN+ReLU is computed on the fly
+// (fused first layer, see ConvArgs::firstw): per chunk a thread evaluates its halo slots (4 channels x 9 taps from a
+// 20x20 input window and the first layer's weights, both kept in LDS behind the two images) and writes them where the
+// LDS-DMA would have put them -- no 64-channel tensor is written by a first-layer kernel or read back here.
+template <int EPI, int NW, int SPLIT, int SRC = 0>
 __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_conv_dma_f32(const ConvArgs p)
 {
+    static_assert(SRC == 0 || (NW == 4 && SPLIT == 0), "fused first layer: 4-wave unsplit kernel only");
+    constexpr int XS = 20;                             // input window edge (halo 18 + 1 on each side)
+    constexpr int XWIN = 416;                          // floats reserved for the window (400 used, 16-byte multiple)
     using G = DmaGeom<NW>;
     constexpr int WBN = 32, NT = G::NT, HR = G::HR, UR = G::UR, DBUF = G::DBUF, DROW = G::DROW, PSTR = G::PSTR;
     extern __shared__ __attribute__((aligned(16))) float smem[];   // the ONLY LDS object (two images)
@@ -149,6 +156,23 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
         const int y1 = gy - p.s1.offY, x1 = gx - p.s1.offX;
         hsec[r] = (data && y1 >= 0 && y1 < p.s1.H && x1 >= 0 && x1 < p.s1.W) ? (y1 * p.s1.W + x1) * p.s1.C + part * 4 : -1;
     }
+    if constexpr (SRC == 1) {
+        // plan of the fused first layer: hcur = index of the slot's 3x3 input window in the LDS copy (-1: the halo pixel
+        // lies outside the image -> zeros, conv2's padding; -2: pad / unused slot -> nothing to write), hsec = channel part
+#pragma unroll
+        for (int r = 0; r < HR; ++r) {
+            const int s = r * NT + tid;
+            const int row = s / G::RSLOTS, k = s - row * G::RSLOTS;
+            const int lk = k < 16 ? k : k - 1;
+            const int pix = lk / G::SPP, part = lk - pix * G::SPP;
+            const bool data = s < G::HUSED && k != 16 && pix < G::HW;
+            const int gy = gy0 + row, gx = gx0 + pix;
+            hcur[r] = !data ? -2 : ((gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) ? row * XS + pix : -1);
+            hsec[r] = part * 4;
+        }
+    }
+    float *const sX = smem + 2 * DBUF;                 // SRC == 1: input window [20][20], then weights [9][64] + bias [64]
+    float *const sW = sX + XWIN;
     const float *srcp = static_cast<const float *>(p.s0.ptr) + (size_t)n * p.s0.H * p.s0.W * p.s0.C;   // next chunk's channels
     const float *base1 = static_cast<const float *>(p.s1.ptr) + (size_t)n * p.s1.H * p.s1.W * p.s1.C;
     if (SPLIT) {
@@ -162,24 +186,49 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
     }
     const float *zsrc = p.zeros;
 
+    // fused first layer: halo slot k of chunk `fc` -> image `buf` (what the LDS-DMA would have copied there)
+    int fchunk = c0;                                   // SRC == 1: chunk the next staged halo belongs to
+    auto first_piece = [&](int k, int buf) {
+        const int w = hcur[k];
+        if (w >= -1) {
+            f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (w >= 0) {
+                const float *xw = sX + w;
+                const float *ww = sW + fchunk * WKC + hsec[k];
+                a = *reinterpret_cast<const f32x4 *>(ww + 9 * 64);                    // folded bias
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx)
+                        a += *reinterpret_cast<const f32x4 *>(ww + (dy * 3 + dx) * 64) * xw[dy * XS + dx];
+                a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
+            }
+            *reinterpret_cast<f32x4 *>(smem + buf * DBUF + (k * NT + tid) * 4) = a;
+        }
+    };
 #define ADN_DMA_BEGIN(c)                                                                       \
     do {                                                                                       \
+        if constexpr (SRC == 0) {                                                              \
         if ((c) == p.nchunk0) {                       /* wave-uniform: switch to the second source */ \
             srcp = base1;                                                                      \
             _Pragma("unroll") for (int r = 0; r < HR; ++r) hcur[r] = hsec[r];                  \
+        }                                                                                      \
         }                                                                                      \
     } while (0)
     // piece k of the HR + UR wave-instructions that copy chunk c into image buf
 #define ADN_DMA_PIECE(k, buf)                                                                  \
     do {                                                                                       \
         float *dst_ = smem + (buf) * DBUF + wave * 256 + (k) * NT * 4;                         \
-        if ((k) < HR) dma16(hcur[(k) < HR ? (k) : 0] >= 0 ? srcp + hcur[(k) < HR ? (k) : 0] : zsrc, dst_); \
-        else dma16(wp + ((k) - HR) * NT * 4, dst_);                                            \
+        if ((k) < HR) {                                                                        \
+            if constexpr (SRC == 1) first_piece((k) < HR ? (k) : 0, (buf));                    \
+            else dma16(hcur[(k) < HR ? (k) : 0] >= 0 ? srcp + hcur[(k) < HR ? (k) : 0] : zsrc, dst_); \
+        } else dma16(wp + ((k) - HR) * NT * 4, dst_);                                          \
     } while (0)
 #define ADN_DMA_END()                                                                          \
     do {                                                                                       \
         srcp += WKC;                                                                           \
         wp += 4096;                                                                            \
+        ++fchunk;                                                                              \
     } while (0)
 #define ADN_DMA(c, buf)                                                                        \
     do {                                                                                       \
@@ -228,6 +277,18 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
             tprev = t_;                                                                      \
         }                                                                                    \
     } while (0)
+    if constexpr (SRC == 1) {
+        // input window (zero outside the image: the FIRST convolution's padding) and first-layer weights -> LDS
+        const float *xin = static_cast<const float *>(p.s0.ptr) + (size_t)n * p.H * p.W;
+        for (int i = tid; i < XS * XS; i += NT) {
+            const int r = i / XS, c = i - r * XS;
+            const int yy = gy0 - 1 + r, xx = gx0 - 1 + c;
+            sX[i] = (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) ? xin[(size_t)yy * p.W + xx] : 0.f;
+        }
+        for (int i = tid; i < 9 * 64; i += NT) sW[i] = p.firstw[i];
+        if (tid < 64) sW[9 * 64 + tid] = p.firstb[tid];
+        __syncthreads();
+    }
     ADN_DMA_BEGIN(c0);                                 // first chunk: the U pieces were issued at the top
 #pragma unroll
     for (int k = 0; k < HR; ++k) ADN_DMA_PIECE(k, 0);
@@ -553,6 +614,24 @@ hipError_t launch_wino_dma_n(ConvKind kind, const ConvArgs &a, hipStream_t st)
                                static_cast<float *>(a2.out), static_cast<float *>(nullptr), a2.ksplit, a2.N, a2.H, a2.W,
                                a2.Cout);
         return hipGetLastError();
+    }
+    if (a2.firstw) {
+        // fused first layer: down1's second conv (+pool) fed by the network input
+        if constexpr (NW == 4) {
+            if (kind != CONV3X3_RELU_POOL || !a2.firstb || a2.ksplit > 1 || a2.nchunk != 8) return hipErrorInvalidValue;
+            constexpr size_t lds1 = lds + (416 + 640) * sizeof(float);
+            static std::atomic<unsigned long long> attr1{0};
+            if (!(attr1.load(std::memory_order_acquire) & bit)) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_conv_dma_f32<CONV3X3_RELU_POOL, 4, 0, 1>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+                if (e != hipSuccess) return e;
+                attr1.fetch_or(bit, std::memory_order_release);
+            }
+            hipLaunchKernelGGL((wino_conv_dma_f32<CONV3X3_RELU_POOL, 4, 0, 1>), dim3((unsigned)nwg), dim3(256), lds1, st, a2);
+            return hipGetLastError();
+        } else {
+            return hipErrorInvalidValue;
+        }
     }
     if (kind == CONV3X3_RELU_DOT) {
         if constexpr (NW == 4) {
