@@ -299,7 +299,7 @@ __device__ __forceinline__ int stft_xcd_remap(int b, int nwg)
 }
 
 // at least 3 waves per SIMD: the register allocation granule is 8, so 169 VGPRs would already drop to 2
-template <int M, int NW, int FPB, int WPE>
+template <int M, int NW, int FPB, int WPE, bool FIT>
 __global__ __launch_bounds__(NW * 64, WPE) void stft_wave_kernel(const float *__restrict__ audio, long L, int hop, int pad,
                                                              long n_frames, int groups_per_clip, int gpb,
                                                              int blocks_per_clip, const float *__restrict__ tables,
@@ -331,7 +331,11 @@ __global__ __launch_bounds__(NW * 64, WPE) void stft_wave_kernel(const float *__
     const int g_first = (lid - clip * blocks_per_clip) * gpb;
     const int g_end = min(g_first + gpb, groups_per_clip);
     const float *aud = audio + (long)clip * L;
-    float *oclip = out + (long)clip * o.clip_stride;
+    // FIT = false (plain STFT): rows = M + 1, row stride = n_frames, no rounding -- kept a compile-time case: the extra
+    // row test and the fp16 round trip per stored value cost 9 % of the kernel when left to run-time flags
+    const long row_stride = FIT ? o.row_stride : n_frames;
+    const int out_rows = FIT ? o.rows : M + 1;
+    float *oclip = out + (long)clip * (FIT ? o.clip_stride : (long)(M + 1) * n_frames);
     v2f *sc = s_sc + slot * SCSZ;
 
     const int Li = (int)L;                                // adn_stft_mag guarantees L < 2^30
@@ -464,7 +468,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void stft_wave_kernel(const float *__
             if constexpr (FPB == 16 && ROWS >= 2 && ROWS <= 32) {
                 constexpr int HALF = ROWS / 2, SUB = 16 / HALF, NBLK = (M + 1 + 31) / 32;
                 const int krow0 = (rid >> 1) + 16 * (rid & 1);
-                const unsigned voff = (unsigned)krow0 * (unsigned)o.row_stride + (unsigned)fr;
+                const unsigned voff = (unsigned)krow0 * (unsigned)row_stride + (unsigned)fr;
                 const float *mp0 = s_mag + krow0 * MAGSTR + fr;
                 if (fglob < n_frames) {
 #pragma unroll
@@ -473,19 +477,19 @@ __global__ __launch_bounds__(NW * 64, WPE) void stft_wave_kernel(const float *__
                         for (int j = 0; j < SUB; ++j) {
                             const int kk = 32 * blk + HALF * j;         // compile-time part of the row index
                             if ((ablate & 2) && kk > 0) break;          // timing experiment: one row block only
-                            if ((kk + 31 <= M || kk + krow0 <= M) && kk + krow0 < o.rows)
-                                (gbase + (long)kk * o.row_stride)[voff] = stft_emit(mp0[kk * MAGSTR], o.quantize);
+                            if ((kk + 31 <= M || kk + krow0 <= M) && (!FIT || kk + krow0 < out_rows))
+                                (gbase + (long)kk * row_stride)[voff] = FIT ? stft_emit(mp0[kk * MAGSTR], o.quantize) : mp0[kk * MAGSTR];
                         }
                 }
             } else {
                 if (fglob < n_frames && !((ablate & 2) && rid > 0)) {
-                    float *op = oclip + (long)rid * o.row_stride + fglob;
+                    float *op = oclip + (long)rid * row_stride + fglob;
                     const float *mp = s_mag + rid * MAGSTR + fr;
-                    const long ostep = (long)ROWS * o.row_stride;
-                    const int kend = M + 1 < o.rows ? M + 1 : o.rows;
+                    const long ostep = (long)ROWS * row_stride;
+                    const int kend = M + 1 < out_rows ? M + 1 : out_rows;
 #pragma unroll 4
                     for (int k = rid; k < ((ablate & 2) ? 1 : kend); k += ROWS) {
-                        *op = stft_emit(*mp, o.quantize);
+                        *op = FIT ? stft_emit(*mp, o.quantize) : *mp;
                         op += ostep;
                         mp += ROWS * MAGSTR;
                     }
@@ -520,7 +524,8 @@ hipError_t launch_wave(const float *audio, int n_clips, long L, int hop, int pad
     const long nwg = bpc * n_clips;
     if (nwg <= 0 || nwg > 0x7fffffffL) return hipErrorInvalidValue;
     const size_t lds = (size_t)((((M + 1) * (FPB + 1) + 1) & ~1) + 2 * SLOTS * exch_size<M>()) * sizeof(float);
-    auto kern = stft_wave_kernel<M, NW, FPB, WPE>;
+    const bool fit = o.quantize != 0;
+    auto kern = fit ? stft_wave_kernel<M, NW, FPB, WPE, true> : stft_wave_kernel<M, NW, FPB, WPE, false>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
