@@ -30,7 +30,8 @@ FAMILIES = {
     "conv_mfma_f16": lambda n: n.startswith(("conv_mfma<_Float16", "conv_dma<_Float16")) and ", 9, " in n,
     "convt_f32": lambda n: n.startswith(("conv_mfma<float", "conv_dma<float")) and ", 1, 4, 2" in n,
     "convt_f16": lambda n: n.startswith(("conv_mfma<_Float16", "conv_dma<_Float16")) and ", 1, 4, 2" in n,
-    "stft_wave_kernel": lambda n: n.startswith("stft_wave_kernel"),
+    "stft_wave_kernel": lambda n: n.startswith("stft_wave_kernel") and not n.rstrip().endswith("true>"),
+    "stft_wave_kernel_fit": lambda n: n.startswith("stft_wave_kernel") and n.rstrip().endswith("true>"),
     "conv_first_kernel": lambda n: n.startswith("conv_first_kernel<float"),
     "conv_out_kernel": lambda n: n.startswith("conv_out_kernel<float"),
     "conv_first_kernel_f16": lambda n: n.startswith("conv_first_kernel<_Float16"),
