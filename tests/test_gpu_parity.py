@@ -70,11 +70,13 @@ def test_unet_matches_oracle_all_blocks(net, dev, weights_np, n, f, t):
     ref, rtaps = oracle.unet_forward(weights_np, x, acc64=True, want_taps=True)
     with torch.no_grad():
         y, taps = net(torch.from_numpy(x).to(dev), return_taps=True)
+        y_plain = net(torch.from_numpy(x).to(dev))      # production path: first and last layers fused into their neighbours
     for name in oracle.TAP_NAMES:
         a = taps[name].cpu().numpy()
         assert a.shape == rtaps[name].shape, name
         assert _rel(a, rtaps[name]) <= TOL, name
     assert _rel(y.cpu().numpy(), ref) <= TOL
+    assert _rel(y_plain.cpu().numpy(), ref) <= TOL
 
 
 def test_unet_full_size_batch64(net, dev, weights_np):
