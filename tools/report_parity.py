@@ -20,3 +20,17 @@ for (n, f, t) in ((2, 16, 16), (2, 33, 47), (1, 64, 80), (1, 257, 188), (1, 513,
     with torch.no_grad():
         y = net(torch.from_numpy(make_input(7, n, f, t)).cuda()).cpu().numpy()
     print(f"{algo:9s} {n}x1x{f}x{t}: max|y-ref|/max|ref| = {np.abs(y - g['y']).max() / np.abs(g['y']).max():.2e}")
+
+# fp16 path (BASELINE configs[4], tolerance 1e-2) and the real-audio configs[0] golden (reference data_loader + model)
+net16 = UNet()
+net16.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+net16 = net16.cuda().eval().set_compute_dtype("f16")
+for (n, f, t) in ((1, 257, 188), (1, 513, 256)):
+    g = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", f"unet_{f}x{t}.npz"))
+    with torch.no_grad():
+        y = net16(torch.from_numpy(make_input(7, n, f, t)).cuda()).cpu().numpy()
+    print(f"{'fp16 path':9s} {n}x1x{f}x{t}: max|y-ref|/max|ref| = {np.abs(y - g['y']).max() / np.abs(g['y']).max():.2e}")
+g = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "config0_real_audio.npz"))
+with torch.no_grad():
+    y = net(torch.from_numpy(g["x_f16"].astype(np.float32)[None, None]).cuda()).cpu().numpy()[0, 0]
+print(f"{algo:9s} config0 real audio 513x256: max|y-ref|/max|ref| = {np.abs(y - g['y']).max() / np.abs(g['y']).max():.2e}")
