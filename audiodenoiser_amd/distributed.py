@@ -30,8 +30,17 @@ def init_from_env(backend: str | None = None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"),
-                                rank=rank, world_size=world)
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        kwargs = {}
+        if backend == "nccl":
+            # one process per GPU: bind this rank to its device BEFORE the communicator exists, so that barriers and
+            # collectives never guess a device (RCCL would otherwise start every rank on device 0)
+            torch.cuda.set_device(local_rank)
+            kwargs["device_id"] = torch.device("cuda", local_rank)
+        try:
+            dist.init_process_group(backend, rank=rank, world_size=world, **kwargs)
+        except TypeError:                                  # torch without the device_id keyword
+            dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
 
