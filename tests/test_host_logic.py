@@ -384,3 +384,42 @@ def test_roofline_accounting():
             assert executed_mfma_flops(l, "winograd") * 2.25 == l["flops"]
         if l["kind"] == "convt":
             assert executed_mfma_flops(l, "direct") == l["flops"]
+
+
+def test_bench_roofline_objects_from_synthetic_timings():
+    """bench.py's roofline / forward objects (no GPU needed): frac = executed matrix-core FLOPs / peak <= 1 for timings at
+    the measured scale, the direct-convolution rate is reported separately, traffic only with a matching library digest."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from audiodenoiser_amd.roofline import PEAK_MFMA_F16_TFLOPS, PEAK_MFMA_F32_TFLOPS, unet_launches
+    launches = unet_launches(513, 256)
+    ms = np.array([0.4 if l["kind"] == "first" else 0.03 if l["kind"] == "out" else 1.2 if l["kind"] == "convt"
+                   else 2.8 * l["flops"] / 9.68e9 for l in launches], dtype=np.float32)
+    r = bench.conv_roofline(ms, 64, "winograd", PEAK_MFMA_F32_TFLOPS, "wino", "wino_conv_dma_f32")
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and 0.5 < r["frac"] <= 1.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["algorithmic"]["tflops"] > r["achieved"] * 2.2            # Winograd executes 1/2.25 of the direct count
+    assert r["traffic"] is None or isinstance(r["traffic"], int)
+    f = bench.forward_summary(ms, 64, "winograd", PEAK_MFMA_F32_TFLOPS)
+    assert set(f["per_launch_ms"]) == {l["name"] for l in launches} and f["frac_mfma_peak_executed"] <= 1.0
+    r16 = bench.conv_roofline(ms * 0.9, 256, "direct_f16", PEAK_MFMA_F16_TFLOPS, "conv_dma", "conv_mfma_f16")
+    assert 0.0 < r16["frac"] <= 1.0 and r16["algorithmic"]["tflops"] <= r16["achieved"] * 1.02
+    # a PMC file of another build must not be reported
+    t, why = bench.tracked_traffic("no_such_kernel")
+    assert t is None and why
+
+
+def test_profile_summary_demangles_float16_kernel_names():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_pmc", os.path.join(ROOT, "tools", "pmc_summary.py"))
+    pmc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pmc)
+    n = pmc.short("_ZN3adn12_GLOBAL__N_18conv_dmaIDF16_Li32ELi64ELi8ELi1ELi9ELi1ELi0ELi4EEEvNS_8ConvArgsE")
+    assert n == "conv_dma<_Float16, 32, 64, 8, 1, 9, 1, 0, 4>"
+    assert pmc.FAMILIES["conv_mfma_f16"](n) and not pmc.FAMILIES["convt_f16"](n)
+    assert pmc.FAMILIES["convt_f32"]("conv_dma<float, 8, 128, 2, 2, 1, 4, 2, 2>")
+    assert pmc.FAMILIES["stft_wave_kernel"]("stft_wave_kernel<512, 4, 16, 3, false>")
+    assert pmc.FAMILIES["stft_wave_kernel_fit"]("stft_wave_kernel<512, 4, 16, 3, true>")
+    assert pmc.short("void adn::(anonymous namespace)::wino_conv_dma_f32<0, 4, 0, 0>(adn::ConvArgs)") == "wino_conv_dma_f32<0, 4, 0, 0>"
