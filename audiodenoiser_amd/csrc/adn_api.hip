@@ -61,6 +61,7 @@ constexpr int CH[5] = {64, 128, 256, 512, 1024};
 struct Conv3x3Layer {
     int Cin, Cout;
     size_t w_off, b_off;   // float offsets into the packed device buffer
+    size_t w4_off;         // F(4x4,3x3) pack of the same weights (fp32 Winograd path), 0 = none
 };
 struct ConvTLayer {
     int Cin, Cout;
@@ -84,6 +85,9 @@ struct adn_unet {
     bool f16 = false;              // fp16 storage + fp16 MFMA (fp32 accumulate); x and y stay fp32 at the ABI
     bool use_wino = true;          // fp32 3x3 layers: Winograd F(2x2,3x3) kernel (false: direct implicit GEMM)
     int wino_bn = 32;              // couts per Winograd workgroup
+    // F(4x4,3x3) kernel where its 32x32 tiles fit the layer (ADN_WINO_TILE when the handle is created: 2 = F(2x2,3x3) for
+    // every layer, 4 = F(4x4,3x3) for every plain / pooled 3x3 layer whatever its size)
+    bool use_wino4 = true, force_wino4 = false;
     // split-K for layers that cannot fill the chip at small batch (ADN_WINO_SPLITK=1 when the handle is created).
     // Off by default: it changes the summation order, and the default path keeps a clip's result bit-identical
     // whatever batch it is computed in.
@@ -158,6 +162,33 @@ void pack_wino3x3(const float *w /*(Cout,Cin,3,3)*/, const std::vector<float> &s
                     (float)U[pos >> 2][pos & 3];
         }
     (void)nct;
+}
+
+// Winograd F(4x4,3x3) weights U = G g G^T (6x6, points 0, +-1, +-2, inf; double precision, BatchNorm scale folded),
+// packed for wino4_conv_f32: [column tile of 32][chunk of 8 channels][pos/4][pass h][cout block][q][cout%16][pos%4] with
+// pos = 6*row + column of U and input channel = chunk*8 + 2q + h: a wave's B-fragment read of one (position group, pass,
+// cout block) is 64 lanes x 16 bytes = 1 KB contiguous.
+void pack_wino4_3x3(const float *w /*(Cout,Cin,3,3)*/, const std::vector<float> &scale, int Cin, int Cout, float *dst)
+{
+    static const double G[6][3] = {{1.0 / 4, 0, 0},           {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                   {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+    const int nchunk = Cin / 8;
+    for (int co = 0; co < Cout; ++co)
+        for (int ci = 0; ci < Cin; ++ci) {
+            const float *g = w + ((size_t)co * Cin + ci) * 9;
+            double tmp[6][3];
+            for (int x = 0; x < 6; ++x)
+                for (int b = 0; b < 3; ++b)
+                    tmp[x][b] = G[x][0] * g[0 * 3 + b] + G[x][1] * g[1 * 3 + b] + G[x][2] * g[2 * 3 + b];
+            const int ct = co / 32, cb = (co % 32) / 16, n16 = co % 16, ch = ci / 8, q = (ci % 8) / 2, h = ci & 1;
+            float *blk = dst + ((size_t)ct * nchunk + ch) * (36 * 8 * 32);
+            for (int x = 0; x < 6; ++x)
+                for (int v = 0; v < 6; ++v) {
+                    const double U = (tmp[x][0] * G[v][0] + tmp[x][1] * G[v][1] + tmp[x][2] * G[v][2]) * (double)scale[co];
+                    const int pos = 6 * x + v;
+                    blk[((((((pos >> 2) * 2 + h) * 2 + cb) * 4 + q) * 16) + n16) * 4 + (pos & 3)] = (float)U;
+                }
+        }
 }
 
 // ConvTranspose2d(k2,s2) as a GEMM with columns col = (i*2+j)*Cout + co, K = Cin.
@@ -251,6 +282,7 @@ adn::ConvArgs conv_args(const adn_unet *h, const Conv3x3Layer &L, adn::ConvKind 
     a.nchunk0 = C0 / g.KC;
     a.nchunk = (C0 + C1) / g.KC;
     a.wpk = h->dev + L.w_off;
+    a.wpk4 = (h->use_wino && h->use_wino4 && L.w4_off) ? h->dev + L.w4_off : nullptr;
     a.bias = h->dev + L.b_off;
     a.out = out;
     a.pool = pool;
@@ -281,6 +313,10 @@ hipError_t launch_conv3(const adn_unet *h, adn::ConvKind kind, const adn::ConvAr
     adn::ConvArgs a2 = a;
     a2.ksplit = (h->allow_split && kind != adn::CONV3X3_RELU_DOT) ? adn::wino_ksplit(adn::wino_workgroups(a), a.nchunk) : 1;
     a2.partial = partial;
+    if (a2.wpk4 && adn::wino4_applicable(kind, a2, h->force_wino4)) {
+        a2.wpk = a2.wpk4;
+        return adn::launch_wino4_conv(kind, a2, st);
+    }
     return adn::launch_wino_conv(kind, a2, st);
 }
 
@@ -383,6 +419,7 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
         t.s1 = adn::ConvSrc{X, 0, 0, 0, 0, 0};
         t.nchunk0 = t.nchunk = upc / g.KC;
         t.wpk = h->dev + TL.w_off;
+        t.wpk4 = nullptr;
         t.bias = h->dev + TL.b_off;
         t.out = Y;
         t.pool = nullptr;
@@ -508,6 +545,10 @@ int adn_unet_create_ex(adn_unet **handle, int device, const float *const *t, int
         h->use_wino = std::strcmp(algo, "direct") != 0;
     if (h->f16) h->use_wino = false;                           // the fp16 path runs the direct fp16-MFMA kernels
     if (const char *sk = std::getenv("ADN_WINO_SPLITK")) h->allow_split = std::atoi(sk) != 0;
+    if (const char *wt = std::getenv("ADN_WINO_TILE")) {
+        h->use_wino4 = std::atoi(wt) != 2;
+        h->force_wino4 = std::atoi(wt) == 4;
+    }
     std::vector<float> host;
     auto reserve = [&](size_t n) {
         const size_t at = host.size();
@@ -524,9 +565,14 @@ int adn_unet_create_ex(adn_unet **handle, int device, const float *const *t, int
         Conv3x3Layer &L = h->c3[li++];
         L.Cin = Cin;
         L.Cout = Cout;
+        L.w4_off = 0;
         if (h->use_wino) {
             L.w_off = reserve((size_t)16 * Cin * Cout);
             pack_wino3x3(t[ti], scale, Cin, Cout, h->wino_bn, host.data() + L.w_off);
+            if (h->use_wino4) {
+                L.w4_off = reserve((size_t)36 * Cin * Cout);
+                pack_wino4_3x3(t[ti], scale, Cin, Cout, host.data() + L.w4_off);
+            }
         } else if (h->f16) {
             L.w_off = reserve(((size_t)9 * Cin * Cout + 1) / 2);
             pack_conv3x3<_Float16>(t[ti], scale, Cin, Cout, reinterpret_cast<_Float16 *>(host.data() + L.w_off));

@@ -20,6 +20,7 @@ struct ConvArgs {
     ConvSrc s0, s1;        // channels [0, s0.C) come from s0, [s0.C, s0.C + s1.C) from s1 (virtual concat)
     int nchunk0, nchunk;   // K-chunks served by s0 / in total
     const void *wpk;       // packed weights, see pack_* in adn_api.hip
+    const void *wpk4;      // fp32 3x3 layers: the same weights packed for the F(4x4,3x3) kernel (pack_wino4_3x3), or nullptr
     const float *bias;     // per GEMM column (BatchNorm folded), always fp32
     void *out;             // NHWC output
     void *pool;            // optional 2x2 max-pooled NHWC output (CONV3X3_RELU_POOL)
@@ -75,6 +76,11 @@ hipError_t launch_conv_mfma(ConvKind kind, const ConvArgs &a, bool f16, hipStrea
 hipError_t launch_wino_conv(ConvKind kind, const ConvArgs &a, hipStream_t st);
 // workgroups of one K split of a Winograd launch (what wino_ksplit() is asked about)
 long wino_workgroups(const ConvArgs &a);
+// Winograd F(4x4,3x3) variant (wino4_kernels.hip): tile 32x32 px x 32 couts, 8-ch chunks, weights from ConvArgs::wpk
+// in pack_wino4_3x3 layout.  wino4_applicable: plain / pooled 3x3 layers whose image the 32x32 tiles cover with little
+// waste; everything else (fused first / last layer, split-K, small images) stays on F(2x2,3x3).
+bool wino4_applicable(ConvKind kind, const ConvArgs &a, bool force);
+hipError_t launch_wino4_conv(ConvKind kind, const ConvArgs &a, hipStream_t st);
 
 // First layer: Conv2d(1 -> 64, 3x3, pad 1) + folded BN + ReLU, fp32 input, NHWC output.  w9x64: [tap][cout].
 hipError_t launch_conv_first(const float *x, const float *w9x64, const float *bias, void *out, bool f16,

@@ -1,0 +1,327 @@
+// Winograd F(4x4,3x3) convolution on the exact-fp32 matrix cores of gfx950.
+//
+// Same role as wino_conv_dma_f32 (wino_kernels.hip) for the 3x3 layers of the reference's DoubleConvLayer
+// (/root/reference/code/model.py:7-20): conv3x3(pad 1) + folded BatchNorm + ReLU (+ MaxPool2d(2), + virtual
+// F.pad/torch.cat of the up path), NHWC fp32 in and out.  F(4x4,3x3) needs 36 multiplies per 4x4 output tile and
+// input channel instead of 144: 4x fewer matrix-core FLOPs than the direct form, 1.78x fewer than F(2x2,3x3):
+//      Y = A^T [ (G g G^T) .* (B^T d B) ] A        summed over input channels, interpolation points 0, +-1, +-2, inf
+//   U = G g G^T (6x6) is precomputed on the host in double precision (BatchNorm scale folded in);
+//   V = B^T d B is computed in registers from the 6x6 patch of the LDS halo by the wave that consumes it;
+//   the 36 element-wise products summed over channels are 36 independent GEMMs
+//      M_pos[tile][cout] += V_pos[tile][cin] * U_pos[cin][cout]
+//   on v_mfma_f32_16x16x4_f32: 16 tiles x 16 couts per MFMA, 36 accumulators (one per position) of identical
+//   layout, so the inverse transform A^T M A is in-lane and a lane's 4x4 output tile holds four max-pool windows.
+// The transforms multiply by 2, 4, 5, 8: results are no longer bit-identical to a direct fp32 sum, the rounding error
+// is ~4x that of F(2x2,3x3) (measured against the reference goldens: 6e-6 of max|y| for the whole network against
+// the 1e-4 bound).
+//
+// Workgroup = 8 waves = 32x32 output pixels (2x2 blocks of 4x4 tiles) x 32 output channels, one per CU (144 accumulator
+// registers per wave leave room for two waves per SIMD):
+//   wave w: tile block (w & 3) x cout block (w >> 2); lane (ti, q) transforms the patch of tile ti for channel pair q
+//   K walked in chunks of 8 input channels, two passes of 4 per chunk (pass h: lane q owns channel 2q + h): halo
+//   (34x34 px x 8 ch) and U (36 pos x 8 ch x 32 couts) are copied global -> LDS by LDS-DMA into one of two images
+//   while the other is consumed; one barrier per chunk.
+#include "adn_internal.h"
+
+#include <atomic>
+
+namespace adn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef const volatile f32x2 __attribute__((address_space(3))) lds4_cv_f32x2;
+typedef const volatile f32x4 __attribute__((address_space(3))) lds4_cv_f32x4;
+
+namespace {
+
+constexpr int KC = 8;                        // input channels per chunk
+constexpr int NT = 512;                      // threads per workgroup
+constexpr int REG = 32;                      // output pixels per workgroup edge
+constexpr int HP = REG + 2;                  // halo edge
+// LDS image (x2).  Halo: row r holds [skew(r) pad slots][34 slots: channels 0-3 of the row's pixels][34 slots: channels
+// 4-7] in RSL = 72 sixteen-byte slots, skew(r) = (r >> 2) & 3.  A patch read (ds_read_b64, served in 32-lane groups over
+// 64 banks) touches one slot per tile: the 4 tile columns are 4 slots apart, the 4 tile rows are 4*72 slots apart = 0
+// mod 16, and the skew moves them to 4 consecutive slots -> 16 different slots mod 16, conflict-free.
+constexpr int RSL = 72;
+constexpr int HR = 5;                        // DMA rounds (512 slots each) covering the 34*72 = 2448 halo slots
+constexpr int HSLOTS = HR * NT;
+constexpr int USLOTS = 36 * KC * 32 / 4;     // 2304 slots: U slab [pos/4][pass][cout block][q][cout%16][pos%4]
+constexpr int UR = (USLOTS + NT - 1) / NT;   // 5 rounds, the last one half full (waves 0-3)
+constexpr int IMG = (HSLOTS + USLOTS) * 4;   // floats per LDS image (77 824 bytes)
+constexpr int SUP = 32;                      // workgroups resident on one XCD (one per CU)
+constexpr size_t LDS_BYTES = (size_t)2 * IMG * sizeof(float);
+
+__device__ __forceinline__ int xcd_remap4(int b, int nwg)
+{
+    const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
+
+__device__ __forceinline__ void dma16(const float *g, float *lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+// B^T x for the points (0, 1, -1, 2, -2, inf), in place:
+//   [ 4  0 -5  0  1  0 ]      twelve operations
+//   [ 0 -4 -4  1  1  0 ]
+//   [ 0  4 -4 -1  1  0 ]
+//   [ 0 -2 -1  2  1  0 ]
+//   [ 0  2 -1 -2  1  0 ]
+//   [ 0  4  0 -5  0  1 ]
+__device__ __forceinline__ void bt6(float &d0, float &d1, float &d2, float &d3, float &d4, float &d5)
+{
+    const float pe = __builtin_fmaf(-4.f, d2, d4);
+    const float po = __builtin_fmaf(-4.f, d1, d3);
+    const float se = d4 - d2;
+    const float so = d3 - d1;
+    const float r0 = __builtin_fmaf(4.f, d0, pe) - d2;
+    const float r5 = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
+    d0 = r0;
+    d1 = pe + po;
+    d2 = pe - po;
+    d3 = __builtin_fmaf(2.f, so, se);
+    d4 = __builtin_fmaf(-2.f, so, se);
+    d5 = r5;
+}
+
+// A^T m (6 -> 4), ten operations:
+//   [ 1 1  1 1  1 0 ]
+//   [ 0 1 -1 2 -2 0 ]
+//   [ 0 1  1 4  4 0 ]
+//   [ 0 1 -1 8 -8 1 ]
+__device__ __forceinline__ void at6(float m0, float m1, float m2, float m3, float m4, float m5, float &y0, float &y1,
+                                    float &y2, float &y3)
+{
+    const float a = m1 + m2, b = m1 - m2, c = m3 + m4, d = m3 - m4;
+    y0 = m0 + a + c;
+    y1 = __builtin_fmaf(2.f, d, b);
+    y2 = __builtin_fmaf(4.f, c, a);
+    y3 = __builtin_fmaf(8.f, d, b) + m5;
+}
+
+template <int EPI>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino4_conv_f32(const ConvArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // the ONLY LDS object (two images)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tb = wave & 3, cb = wave >> 2;                       // tile block (2x2 of them), cout block of 16
+    const int by = tb >> 1, bx = tb & 1;
+    const int ti = lane & 15, q = lane >> 4;
+
+    // workgroup -> (pixel tile, cout tile): SUP consecutive ids (after the XCD remap) run together on one XCD and form
+    // a supertile of gc cout tiles x gp pixel tiles, so every U slab and every halo is an L2 hit for all but one of them
+    const int lid = xcd_remap4(blockIdx.x, gridDim.x);
+    const int gc = p.nct < 8 ? p.nct : 8, gp = SUP / gc;
+    const int ncg = p.nct / gc;
+    const int sg = lid / SUP, wl = lid - sg * SUP;
+    const int ct = (sg % ncg) * gc + wl % gc;
+    int pt = (sg / ncg) * gp + wl / gc;
+    if (pt >= p.N * p.tilesY * p.tilesX) return;          // padding of the last supertile (whole workgroup exits)
+    const int tx = pt % p.tilesX;
+    pt /= p.tilesX;
+    const int ty = pt % p.tilesY;
+    const int n = pt / p.tilesY;
+    const int gy0 = ty * REG - 1, gx0 = tx * REG - 1;
+
+    // U slab of the first chunk: needs no plan, flies under the index arithmetic below
+    const float *wp = static_cast<const float *>(p.wpk) + (size_t)ct * p.nchunk * (USLOTS * 4) + tid * 4;
+#pragma unroll
+    for (int k = 0; k < UR; ++k)
+        if (k * NT + wave * 64 < USLOTS) dma16(wp + k * NT * 4, smem + (HSLOTS + k * NT + wave * 64) * 4);
+
+    // DMA plan of the halo: slot s = r*NT + tid -> (row, pixel, channel half); offsets into the current source, -1 = zeros
+    int hcur[HR];
+    auto plan = [&](const ConvSrc &s) {
+#pragma unroll
+        for (int r = 0; r < HR; ++r) {
+            const int sl = r * NT + tid;
+            const int row = sl / RSL, j = sl - row * RSL;
+            const int jj = j - ((row >> 2) & 3);
+            const int half = jj >= HP ? 1 : 0;
+            const int c = jj - half * HP;
+            const bool data = row < HP && jj >= 0 && jj < 2 * HP;
+            const int y = gy0 + row - s.offY, x = gx0 + c - s.offX;
+            hcur[r] = (data && y >= 0 && y < s.H && x >= 0 && x < s.W) ? (y * s.W + x) * s.C + half * 4 : -1;
+        }
+    };
+    plan(p.s0);
+    const float *srcp = static_cast<const float *>(p.s0.ptr) + (size_t)n * p.s0.H * p.s0.W * p.s0.C;
+    const float *zsrc = p.zeros;
+
+#define W4_DMA_BEGIN(c)                                                                        \
+    do {                                                                                       \
+        if ((c) == p.nchunk0) {                       /* wave-uniform: switch to the second source (virtual concat) */ \
+            srcp = static_cast<const float *>(p.s1.ptr) + (size_t)n * p.s1.H * p.s1.W * p.s1.C; \
+            plan(p.s1);                                                                        \
+        }                                                                                      \
+    } while (0)
+    // piece k of the HR + UR wave-instructions that copy a chunk into image buf
+#define W4_DMA_PIECE(k, buf)                                                                   \
+    do {                                                                                       \
+        float *dst_ = smem + (buf) * IMG + ((k) * NT + wave * 64) * 4;                         \
+        if ((k) < HR) dma16(hcur[(k) < HR ? (k) : 0] >= 0 ? srcp + hcur[(k) < HR ? (k) : 0] : zsrc, dst_); \
+        else if (((k) - HR) * NT + wave * 64 < USLOTS) dma16(wp + ((k) - HR) * NT * 4, dst_);  \
+    } while (0)
+#define W4_DMA_END()                                                                           \
+    do {                                                                                       \
+        srcp += KC;                                                                            \
+        wp += USLOTS * 4;                                                                      \
+    } while (0)
+
+    const float bias_r = p.bias[ct * 32 + 16 * cb + ti];
+
+    f32x4 acc[36];
+#pragma unroll
+    for (int s = 0; s < 36; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // patch reads: lane (ti, q) reads channels 2q, 2q+1 (one ds_read_b64) of the 6x6 pixels of tile (ti >> 2, ti & 3)
+    const int tyl = ti >> 2, txl = ti & 3;
+    const int a_base = ((16 * by + 4 * tyl) * RSL + (q >> 1) * HP + 16 * bx + 4 * txl) * 4 + 2 * (q & 1);
+    const int a_lo = a_base + tyl * 4;                      // rows 0-3 of the patch: skew = tile row
+    const int a_hi = a_base + ((tyl + 1) & 3) * 4;          // rows 4-5: the next group of four halo rows
+    const int b_lane = (cb * 64 + lane) * 4;                // U slab [pos/4][pass][cout block][q][cout%16][pos%4]
+
+    W4_DMA_BEGIN(0);
+#pragma unroll
+    for (int k = 0; k < HR; ++k) W4_DMA_PIECE(k, 0);
+    W4_DMA_END();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int c = 0; c < p.nchunk; ++c) {
+        const bool more = c + 1 < p.nchunk;
+        const int nb = (c + 1) & 1;
+        if (more) W4_DMA_BEGIN(c + 1);
+        const float *sA = smem + (c & 1) * IMG;
+        const float *sB = sA + HSLOTS * 4;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float V[36];
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int b = 0; b < 6; ++b) {
+                    const f32x2 v = *(lds4_cv_f32x2 *)(sA + (a < 4 ? a_lo : a_hi) + (a * RSL + b) * 4);
+                    V[a * 6 + b] = h ? v.y : v.x;
+                }
+#pragma unroll
+            for (int a = 0; a < 6; ++a) bt6(V[a * 6 + 0], V[a * 6 + 1], V[a * 6 + 2], V[a * 6 + 3], V[a * 6 + 4], V[a * 6 + 5]);
+#pragma unroll
+            for (int b = 0; b < 6; ++b) bt6(V[0 * 6 + b], V[1 * 6 + b], V[2 * 6 + b], V[3 * 6 + b], V[4 * 6 + b], V[5 * 6 + b]);
+            // B fragments: one ds_read_b128 per group of four positions, read one group ahead of its MFMAs (the empty
+            // asm consumes the landed fragment, so the next read is issued behind that wait and flies under the MFMAs)
+            f32x4 u[2];
+#define W4_LOADU(dst, g) dst = *(lds4_cv_f32x4 *)(sB + b_lane + (((g) * 2 + h) * 2) * 256)
+#define W4_LANDED(x) asm volatile("" ::"v"(x.w))
+            W4_LOADU(u[0], 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < 9; ++g) {
+                W4_LANDED(u[g & 1]);
+                if (g < 8) W4_LOADU(u[(g + 1) & 1], g + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more && g < 5) W4_DMA_PIECE(5 * h + g, nb);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    acc[4 * g + s] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[4 * g + s], u[g & 1][s], acc[4 * g + s], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#undef W4_LOADU
+#undef W4_LANDED
+        }
+        if (more) W4_DMA_END();
+        // every wave: its own DMA writes have landed (vmcnt); then all waves: image c is free, image c+1 complete
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#undef W4_DMA_BEGIN
+#undef W4_DMA_PIECE
+#undef W4_DMA_END
+
+    // epilogue: lane (ti, q) holds cout 16*cb + ti of the tiles (row q, columns 0..3) of its block, register r = column
+    const int Hp = p.H >> 1, Wp = p.W >> 1;
+    const int col = ct * 32 + 16 * cb + ti;
+    float *ob = static_cast<float *>(p.out) + (size_t)n * p.H * p.W * p.Cout + col;
+    float *pb = (EPI == CONV3X3_RELU_POOL) ? static_cast<float *>(p.pool) + (size_t)n * Hp * Wp * p.Cout + col : nullptr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float w[6][4];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            at6(acc[i * 6 + 0][r], acc[i * 6 + 1][r], acc[i * 6 + 2][r], acc[i * 6 + 3][r], acc[i * 6 + 4][r], acc[i * 6 + 5][r],
+                w[i][0], w[i][1], w[i][2], w[i][3]);
+        float y[4][4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) at6(w[0][v], w[1][v], w[2][v], w[3][v], w[4][v], w[5][v], y[0][v], y[1][v], y[2][v], y[3][v]);
+        const int gy = ty * REG + 16 * by + 4 * q, gx = tx * REG + 16 * bx + 4 * r;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                y[a][b] = fmaxf(y[a][b] + bias_r, 0.f);
+                if (gy + a < p.H && gx + b < p.W) ob[((size_t)(gy + a) * p.W + gx + b) * p.Cout] = y[a][b];
+            }
+        if (EPI == CONV3X3_RELU_POOL) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const float mx = fmaxf(fmaxf(y[2 * a][2 * b], y[2 * a][2 * b + 1]), fmaxf(y[2 * a + 1][2 * b], y[2 * a + 1][2 * b + 1]));
+                    const int py = (gy >> 1) + a, px = (gx >> 1) + b;
+                    if (py < Hp && px < Wp) pb[((size_t)py * Wp + px) * p.Cout] = mx;
+                }
+        }
+    }
+}
+
+}  // namespace
+
+// F(4x4,3x3) serves a layer when its 32x32-pixel workgroup tiles waste little of the image: at most a quarter of the
+// tiled area outside the image (the 32x16 bottleneck and small images stay on F(2x2,3x3), whose tiles are 16x16).
+// force: every plain / pooled layer whatever its size (ADN_WINO_TILE=4; parity tests of the tile-edge handling).
+bool wino4_applicable(ConvKind kind, const ConvArgs &a, bool force)
+{
+    if (kind != CONV3X3_RELU && kind != CONV3X3_RELU_POOL) return false;
+    if (a.firstw || a.ksplit > 1 || (a.Cout & 31) || a.nchunk < 1) return false;
+    const long th = (a.H + REG - 1) / REG, tw = (a.W + REG - 1) / REG;
+    return force || th * tw * REG * REG * 3 <= (long)a.H * a.W * 4;
+}
+
+hipError_t launch_wino4_conv(ConvKind kind, const ConvArgs &a, hipStream_t st)
+{
+    if (!wino4_applicable(kind, a, true) || !a.zeros) return hipErrorInvalidValue;
+    ConvArgs a2 = a;
+    a2.tilesY = (a.H + REG - 1) / REG;
+    a2.tilesX = (a.W + REG - 1) / REG;
+    a2.nct = a.Cout / 32;
+    const long gc = a2.nct < 8 ? a2.nct : 8, gp = SUP / gc;
+    const long ptiles = (long)a2.N * a2.tilesY * a2.tilesX;
+    const long nwg = ((ptiles + gp - 1) / gp) * gp * a2.nct;
+    if (nwg <= 0 || nwg > 0x7fffffffL) return hipErrorInvalidValue;
+    static std::atomic<unsigned long long> attr_mask{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(attr_mask.load(std::memory_order_acquire) & bit)) {
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_conv_f32<CONV3X3_RELU_POOL>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_conv_f32<CONV3X3_RELU>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e1 != hipSuccess) return e1;
+        if (e2 != hipSuccess) return e2;
+        attr_mask.fetch_or(bit, std::memory_order_release);
+    }
+    if (kind == CONV3X3_RELU_POOL)
+        hipLaunchKernelGGL(wino4_conv_f32<CONV3X3_RELU_POOL>, dim3((unsigned)nwg), dim3(NT), LDS_BYTES, st, a2);
+    else
+        hipLaunchKernelGGL(wino4_conv_f32<CONV3X3_RELU>, dim3((unsigned)nwg), dim3(NT), LDS_BYTES, st, a2);
+    return hipGetLastError();
+}
+
+}  // namespace adn

@@ -188,17 +188,21 @@ def test_c_abi_rejects_misaligned_buffers_and_keeps_the_current_device(net, dev)
     assert torch.cuda.current_device() == before
 
 
-@pytest.mark.parametrize("algo", ["direct", "winograd"])
+@pytest.mark.parametrize("algo", ["direct", "winograd", "winograd_f2", "winograd_f4"])
 def test_unet_both_conv_algorithms(dev, weights_np, golden_dir, algo, monkeypatch):
-    """The 3x3 layers have two kernels: Winograd F(2x2,3x3) (default) and the direct implicit GEMM
-    (ADN_CONV_ALGO=direct, read when the handle is created).  Both must meet the same tolerance, on a shape with
-    pads in both dimensions and on the reference's own test shape."""
+    """The 3x3 layers have three kernels: Winograd F(4x4,3x3) where its 32x32 tiles fit and F(2x2,3x3) elsewhere
+    (default), and the direct implicit GEMM (ADN_CONV_ALGO=direct, read when the handle is created).
+    ADN_WINO_TILE=2 / 4 pin one Winograd form for every plain 3x3 layer (4: also where the tiles overhang most of the
+    image).  All must meet the same tolerance, on a shape with pads in both dimensions and on the reference's own
+    test shape."""
     from audiodenoiser_amd.model import UNet
     from audiodenoiser_amd.weights import make_input
+    monkeypatch.delenv("ADN_CONV_ALGO", raising=False)
+    monkeypatch.delenv("ADN_WINO_TILE", raising=False)
     if algo == "direct":
         monkeypatch.setenv("ADN_CONV_ALGO", "direct")
-    else:
-        monkeypatch.delenv("ADN_CONV_ALGO", raising=False)
+    elif algo != "winograd":
+        monkeypatch.setenv("ADN_WINO_TILE", algo[-1])
     m = UNet(1, 1)
     m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in weights_np.items()}, strict=True)
     m = m.to(dev).eval()
@@ -207,6 +211,29 @@ def test_unet_both_conv_algorithms(dev, weights_np, golden_dir, algo, monkeypatc
         with torch.no_grad():
             y = m(torch.from_numpy(make_input(7, n, f, t)).to(dev)).cpu().numpy()
         assert _rel(y, g["y"]) <= TOL, (algo, f, t)
+
+
+@pytest.mark.parametrize("n,f,t", [(3, 20, 36), (1, 48, 100), (2, 31, 16), (1, 16, 130), (2, 97, 70)])
+def test_unet_f4_every_block_forced(dev, weights_np, n, f, t, monkeypatch):
+    """F(4x4,3x3) forced onto every plain / pooled 3x3 layer (ADN_WINO_TILE=4), odd shapes: tile overhang in both
+    dimensions, images smaller than one 32x32 tile, virtual pad + concat sources; every block output against the oracle."""
+    import oracle
+    from audiodenoiser_amd.model import UNet
+    from audiodenoiser_amd.weights import make_input
+    monkeypatch.delenv("ADN_CONV_ALGO", raising=False)
+    monkeypatch.setenv("ADN_WINO_TILE", "4")
+    m = UNet(1, 1)
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in weights_np.items()}, strict=True)
+    m = m.to(dev).eval()
+    x = make_input(23, n, f, t)
+    ref, rtaps = oracle.unet_forward(weights_np, x, acc64=True, want_taps=True)
+    with torch.no_grad():
+        y, taps = m(torch.from_numpy(x).to(dev), return_taps=True)
+        y_plain = m(torch.from_numpy(x).to(dev))
+    for name in oracle.TAP_NAMES:
+        assert _rel(taps[name].cpu().numpy(), rtaps[name]) <= TOL, name
+    assert _rel(y.cpu().numpy(), ref) <= TOL
+    assert _rel(y_plain.cpu().numpy(), ref) <= TOL
 
 
 def test_unet_weights_follow_state_dict_updates(dev, weights_np):
