@@ -165,9 +165,10 @@ void pack_wino3x3(const float *w /*(Cout,Cin,3,3)*/, const std::vector<float> &s
 }
 
 // Winograd F(4x4,3x3) weights U = G g G^T (6x6, points 0, +-1, +-2, inf; double precision, BatchNorm scale folded),
-// packed for wino4_conv_f32: [column tile of 32][chunk of 8 channels][pos/4][pass h][cout block][q][cout%16][pos%4] with
-// pos = 6*row + column of U and input channel = chunk*8 + 2q + h: a wave's B-fragment read of one (position group, pass,
-// cout block) is 64 lanes x 16 bytes = 1 KB contiguous.
+// packed for wino4_conv_f32: [column tile of 32][chunk of 8 channels][jh][group g][pass h][q][cout%16][k] with input channel
+// = chunk*8 + 2q + h.  A wave owns the positions (row i, column j) of U with j / 3 = jh, numbered p = 3i + j%3; float k of
+// group g is position p = 2g + k/2 for cout block (k & 1) ^ jh (block 0 of a wave is the one it finishes, = jh): a wave's
+// B-fragment read of one group and pass is 64 lanes x 16 bytes = 1 KB contiguous.
 void pack_wino4_3x3(const float *w /*(Cout,Cin,3,3)*/, const std::vector<float> &scale, int Cin, int Cout, float *dst)
 {
     static const double G[6][3] = {{1.0 / 4, 0, 0},           {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
@@ -185,8 +186,8 @@ void pack_wino4_3x3(const float *w /*(Cout,Cin,3,3)*/, const std::vector<float> 
             for (int x = 0; x < 6; ++x)
                 for (int v = 0; v < 6; ++v) {
                     const double U = (tmp[x][0] * G[v][0] + tmp[x][1] * G[v][1] + tmp[x][2] * G[v][2]) * (double)scale[co];
-                    const int pos = 6 * x + v;
-                    blk[((((((pos >> 2) * 2 + h) * 2 + cb) * 4 + q) * 16) + n16) * 4 + (pos & 3)] = (float)U;
+                    const int jh = v / 3, pp = 3 * x + v % 3, grp = pp >> 1, k = ((pp & 1) << 1) | (cb ^ jh);
+                    blk[(((((jh * 9 + grp) * 2 + h) * 4 + q) * 16) + n16) * 4 + k] = (float)U;
                 }
         }
 }

@@ -17,13 +17,15 @@
 //
 // Workgroup = 8 waves = 32x32 output pixels (2x2 blocks of 4x4 tiles) x 32 output channels, one per CU (144 accumulator
 // registers per wave leave room for two waves per SIMD):
-//   wave w: tile block (w & 3) x cout block (w >> 2); lane (ti, q) transforms the patch of tile ti for channel pair q
+//   wave w: tile block (w >> 1) x position half (w & 1: columns 0-2 or 3-5 of the 6x6 transform domain) x 32 couts;
+//   lane (ti, q) transforms the patch of tile ti for channel pair q
 //   K walked in chunks of 8 input channels, two passes of 4 per chunk (pass h: lane q owns channel 2q + h): halo
 //   (34x34 px x 8 ch) and U (36 pos x 8 ch x 32 couts) are copied global -> LDS by LDS-DMA into one of two images
 //   while the other is consumed; one barrier per chunk.
 #include "adn_internal.h"
 
 #include <atomic>
+#include <cstdlib>
 
 namespace adn {
 
@@ -45,7 +47,7 @@ constexpr int HP = REG + 2;                  // halo edge
 constexpr int RSL = 72;
 constexpr int HR = 5;                        // DMA rounds (512 slots each) covering the 34*72 = 2448 halo slots
 constexpr int HSLOTS = HR * NT;
-constexpr int USLOTS = 36 * KC * 32 / 4;     // 2304 slots: U slab [pos/4][pass][cout block][q][cout%16][pos%4]
+constexpr int USLOTS = 36 * KC * 32 / 4;     // 2304 slots: U slab, see pack_wino4_3x3 (adn_api.hip)
 constexpr int UR = (USLOTS + NT - 1) / NT;   // 5 rounds, the last one half full (waves 0-3)
 constexpr int IMG = (HSLOTS + USLOTS) * 4;   // floats per LDS image (77 824 bytes)
 constexpr int SUP = 32;                      // workgroups resident on one XCD (one per CU)
@@ -101,7 +103,9 @@ __device__ __forceinline__ void at6(float m0, float m1, float m2, float m3, floa
     y3 = __builtin_fmaf(8.f, d, b) + m5;
 }
 
-template <int EPI>
+// ABL: timing experiments (-DADN_EXPERIMENTS builds, ADN_WINO4_ABLATE): 1 no copies after the first chunk, 2 no patch
+// reads / transform, 4 no transform, 8 no barrier, 16 no B-fragment reads; results are wrong by design.  0 in production.
+template <int EPI, int ABL = 0>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino4_conv_f32(const ConvArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];   // the ONLY LDS object (two images)
@@ -109,7 +113,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tb = wave & 3, cb = wave >> 2;                       // tile block (2x2 of them), cout block of 16
+    // wave = (tile block, position half): the two waves of a tile block split the 36 positions by transform-domain
+    // column (jh = 0: columns 0-2, jh = 1: columns 3-5) and each owns all 32 couts of its 18 positions.  The row stage of
+    // V = B^T d B then costs each wave only its own three outputs per patch row (6 of the 12 operations, from 5 of the 6
+    // pixel columns) and the column stage only its own three columns: 72 operations per tile and channel and wave, no
+    // transform work is duplicated inside the workgroup.
+    const int tb = wave >> 1, jh = wave & 1;
     const int by = tb >> 1, bx = tb & 1;
     const int ti = lane & 15, q = lane >> 4;
 
@@ -173,18 +182,22 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         wp += USLOTS * 4;                                                                      \
     } while (0)
 
-    const float bias_r = p.bias[ct * 32 + 16 * cb + ti];
+    // after the epilogue's exchange this wave finishes cout block jh of its tile block
+    const float bias_r = p.bias[ct * 32 + 16 * jh + ti];
 
-    f32x4 acc[36];
+    f32x4 acc[2][18];                                  // [cout block: 0 = the one this wave finishes (jh), 1 = the partner's][position]
 #pragma unroll
-    for (int s = 0; s < 36; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int s = 0; s < 18; ++s) acc[j][s] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // patch reads: lane (ti, q) reads channels 2q, 2q+1 (one ds_read_b64) of the 6x6 pixels of tile (ti >> 2, ti & 3)
+    // patch reads: lane (ti, q) reads channels 2q, 2q+1 (one ds_read_b64) of pixel columns jh .. jh+4 of the 6 patch rows
+    // of tile (ti >> 2, ti & 3)
     const int tyl = ti >> 2, txl = ti & 3;
-    const int a_base = ((16 * by + 4 * tyl) * RSL + (q >> 1) * HP + 16 * bx + 4 * txl) * 4 + 2 * (q & 1);
+    const int a_base = ((16 * by + 4 * tyl) * RSL + (q >> 1) * HP + 16 * bx + 4 * txl + jh) * 4 + 2 * (q & 1);
     const int a_lo = a_base + tyl * 4;                      // rows 0-3 of the patch: skew = tile row
     const int a_hi = a_base + ((tyl + 1) & 3) * 4;          // rows 4-5: the next group of four halo rows
-    const int b_lane = (cb * 64 + lane) * 4;                // U slab [pos/4][pass][cout block][q][cout%16][pos%4]
+    const int b_lane = (jh * 9 * 2 * 64 + lane) * 4;        // U slab [jh][group of 2 positions][pass][q][cout%16][pos%2][cout block]
 
     W4_DMA_BEGIN(0);
 #pragma unroll
@@ -193,43 +206,77 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    constexpr int abl = ABL;
     for (int c = 0; c < p.nchunk; ++c) {
-        const bool more = c + 1 < p.nchunk;
+        const bool more = c + 1 < p.nchunk && !((abl & 1) && c >= 1);
         const int nb = (c + 1) & 1;
         if (more) W4_DMA_BEGIN(c + 1);
         const float *sA = smem + (c & 1) * IMG;
         const float *sB = sA + HSLOTS * 4;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            float V[36];
+        // one read serves both passes: .x = channel 2q (pass 0), .y = channel 2q + 1 (pass 1)
+        f32x2 d[6][5];
+        if (!(abl & 2)) {
 #pragma unroll
             for (int a = 0; a < 6; ++a)
 #pragma unroll
-                for (int b = 0; b < 6; ++b) {
-                    const f32x2 v = *(lds4_cv_f32x2 *)(sA + (a < 4 ? a_lo : a_hi) + (a * RSL + b) * 4);
-                    V[a * 6 + b] = h ? v.y : v.x;
+                for (int k = 0; k < 5; ++k) d[a][k] = *(lds4_cv_f32x2 *)(sA + (a < 4 ? a_lo : a_hi) + (a * RSL + k) * 4);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float V[18];                                // [row i of the transform domain][own column]
+            if (abl & 2) {
+#pragma unroll
+                for (int i = 0; i < 18; ++i) V[i] = bias_r + (float)i;
+            } else if (abl & 4) {
+#pragma unroll
+                for (int i = 0; i < 18; ++i) V[i] = h ? d[i / 3][i % 3].y : d[i / 3][i % 3].x;
+            } else {
+                // row stage, own three outputs (rows of B^T in the header comment; L_k = pixel column jh + k)
+                if (jh == 0) {
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) {
+                        const float L0 = h ? d[a][0].y : d[a][0].x, L1 = h ? d[a][1].y : d[a][1].x, L2 = h ? d[a][2].y : d[a][2].x,
+                                    L3 = h ? d[a][3].y : d[a][3].x, L4 = h ? d[a][4].y : d[a][4].x;
+                        const float pe = __builtin_fmaf(-4.f, L2, L4), po = __builtin_fmaf(-4.f, L1, L3);
+                        V[a * 3 + 0] = __builtin_fmaf(4.f, L0, pe) - L2;
+                        V[a * 3 + 1] = pe + po;
+                        V[a * 3 + 2] = pe - po;
+                    }
+                } else {
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) {
+                        const float L0 = h ? d[a][0].y : d[a][0].x, L1 = h ? d[a][1].y : d[a][1].x, L2 = h ? d[a][2].y : d[a][2].x,
+                                    L3 = h ? d[a][3].y : d[a][3].x, L4 = h ? d[a][4].y : d[a][4].x;
+                        const float se = L3 - L1, so = L2 - L0;
+                        V[a * 3 + 0] = __builtin_fmaf(2.f, so, se);
+                        V[a * 3 + 1] = __builtin_fmaf(-2.f, so, se);
+                        V[a * 3 + 2] = __builtin_fmaf(4.f, L0, __builtin_fmaf(-5.f, L2, L4));
+                    }
                 }
+                // column stage
 #pragma unroll
-            for (int a = 0; a < 6; ++a) bt6(V[a * 6 + 0], V[a * 6 + 1], V[a * 6 + 2], V[a * 6 + 3], V[a * 6 + 4], V[a * 6 + 5]);
-#pragma unroll
-            for (int b = 0; b < 6; ++b) bt6(V[0 * 6 + b], V[1 * 6 + b], V[2 * 6 + b], V[3 * 6 + b], V[4 * 6 + b], V[5 * 6 + b]);
-            // B fragments: one ds_read_b128 per group of four positions, read one group ahead of its MFMAs (the empty
-            // asm consumes the landed fragment, so the next read is issued behind that wait and flies under the MFMAs)
+                for (int b = 0; b < 3; ++b) bt6(V[0 * 3 + b], V[1 * 3 + b], V[2 * 3 + b], V[3 * 3 + b], V[4 * 3 + b], V[5 * 3 + b]);
+            }
+            // B fragments: one ds_read_b128 per group of two positions x two cout blocks, read one group ahead of its
+            // MFMAs (the empty asm consumes the landed fragment, so the next read is issued behind that wait and flies
+            // under the MFMAs)
             f32x4 u[2];
-#define W4_LOADU(dst, g) dst = *(lds4_cv_f32x4 *)(sB + b_lane + (((g) * 2 + h) * 2) * 256)
+#define W4_LOADU(dst, g) dst = *(lds4_cv_f32x4 *)(sB + b_lane + ((g) * 2 + h) * 256)
 #define W4_LANDED(x) asm volatile("" ::"v"(x.w))
-            W4_LOADU(u[0], 0);
+            if (abl & 16) u[0] = u[1] = f32x4{bias_r, 1.f, 2.f, 3.f};
+            else W4_LOADU(u[0], 0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int g = 0; g < 9; ++g) {
                 W4_LANDED(u[g & 1]);
-                if (g < 8) W4_LOADU(u[(g + 1) & 1], g + 1);
+                if (g < 8 && !(abl & 16)) W4_LOADU(u[(g + 1) & 1], g + 1);
                 __builtin_amdgcn_sched_barrier(0);
-                if (more && g < 5) W4_DMA_PIECE(5 * h + g, nb);
+                if (more && ((9 * h + g) % 2 == 0 || 9 * h + g == 17)) W4_DMA_PIECE((9 * h + g == 17 ? 9 : (9 * h + g) / 2), nb);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
-                    acc[4 * g + s] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[4 * g + s], u[g & 1][s], acc[4 * g + s], 0, 0, 0);
+                    acc[s & 1][2 * g + (s >> 1)] =
+                        __builtin_amdgcn_mfma_f32_16x16x4f32(V[2 * g + (s >> 1)], u[g & 1][s], acc[s & 1][2 * g + (s >> 1)], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #undef W4_LOADU
@@ -238,35 +285,67 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         if (more) W4_DMA_END();
         // every wave: its own DMA writes have landed (vmcnt); then all waves: image c is free, image c+1 complete
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (!(abl & 8)) __syncthreads();
     }
 #undef W4_DMA_BEGIN
 #undef W4_DMA_PIECE
 #undef W4_DMA_END
 
-    // epilogue: lane (ti, q) holds cout 16*cb + ti of the tiles (row q, columns 0..3) of its block, register r = column
+    // ---- epilogue ----
+    // Y = A^T M A = sum over the transform-domain columns j of (A^T M)[.][j] * A^T[v][j]: each wave forms the sum over its
+    // own three columns for both cout blocks, hands the partner's block over through LDS (the images are free: the loop
+    // ended with a barrier) and finishes its own: lane (ti, q) = cout 16*jh + ti of the tiles (row q, columns r = 0..3).
+    auto partial = [&](const f32x4 *m, int r, float (&y)[4][4]) {
+        float w[4][3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+            at6(m[0 * 3 + b][r], m[1 * 3 + b][r], m[2 * 3 + b][r], m[3 * 3 + b][r], m[4 * 3 + b][r], m[5 * 3 + b][r], w[0][b], w[1][b],
+                w[2][b], w[3][b]);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            if (jh == 0) {                              // columns 0, 1, 2 of A^T: (1 1 1), (0 1 -1), (0 1 1), (0 1 -1)
+                const float s = w[a][1] + w[a][2], t = w[a][1] - w[a][2];
+                y[a][0] = w[a][0] + s;
+                y[a][1] = t;
+                y[a][2] = s;
+                y[a][3] = t;
+            } else {                                    // columns 3, 4, 5: (1 1 0), (2 -2 0), (4 4 0), (8 -8 1)
+                const float s = w[a][0] + w[a][1], t = w[a][0] - w[a][1];
+                y[a][0] = s;
+                y[a][1] = 2.f * t;
+                y[a][2] = 4.f * s;
+                y[a][3] = __builtin_fmaf(8.f, t, w[a][2]);
+            }
+        }
+    };
+    float *xb = smem + ((tb * 2 + jh) * 16 * 64 + lane) * 4;           // this wave's outgoing block [16 pieces][64 lanes][4]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float y[4][4];
+        partial(acc[1], r, y);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) *reinterpret_cast<f32x4 *>(xb + (r * 4 + a) * 256) = f32x4{y[a][0], y[a][1], y[a][2], y[a][3]};
+    }
+    __syncthreads();
+    const float *xr = smem + ((tb * 2 + (jh ^ 1)) * 16 * 64 + lane) * 4;  // the partner's block: its sum for OUR cout block
     const int Hp = p.H >> 1, Wp = p.W >> 1;
-    const int col = ct * 32 + 16 * cb + ti;
+    const int col = ct * 32 + 16 * jh + ti;
     float *ob = static_cast<float *>(p.out) + (size_t)n * p.H * p.W * p.Cout + col;
     float *pb = (EPI == CONV3X3_RELU_POOL) ? static_cast<float *>(p.pool) + (size_t)n * Hp * Wp * p.Cout + col : nullptr;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        float w[6][4];
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-            at6(acc[i * 6 + 0][r], acc[i * 6 + 1][r], acc[i * 6 + 2][r], acc[i * 6 + 3][r], acc[i * 6 + 4][r], acc[i * 6 + 5][r],
-                w[i][0], w[i][1], w[i][2], w[i][3]);
         float y[4][4];
-#pragma unroll
-        for (int v = 0; v < 4; ++v) at6(w[0][v], w[1][v], w[2][v], w[3][v], w[4][v], w[5][v], y[0][v], y[1][v], y[2][v], y[3][v]);
+        partial(acc[0], r, y);
         const int gy = ty * REG + 16 * by + 4 * q, gx = tx * REG + 16 * bx + 4 * r;
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < 4; ++a) {
+            const f32x4 o = *reinterpret_cast<const f32x4 *>(xr + (r * 4 + a) * 256);
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                y[a][b] = fmaxf(y[a][b] + bias_r, 0.f);
+                y[a][b] = fmaxf(y[a][b] + o[b] + bias_r, 0.f);
                 if (gy + a < p.H && gx + b < p.W) ob[((size_t)(gy + a) * p.W + gx + b) * p.Cout] = y[a][b];
             }
+        }
         if (EPI == CONV3X3_RELU_POOL) {
 #pragma unroll
             for (int a = 0; a < 2; ++a)
@@ -304,6 +383,10 @@ hipError_t launch_wino4_conv(ConvKind kind, const ConvArgs &a, hipStream_t st)
     const long ptiles = (long)a2.N * a2.tilesY * a2.tilesX;
     const long nwg = ((ptiles + gp - 1) / gp) * gp * a2.nct;
     if (nwg <= 0 || nwg > 0x7fffffffL) return hipErrorInvalidValue;
+    a2.ablate = 0;
+#ifdef ADN_EXPERIMENTS
+    { const char *ab = std::getenv("ADN_WINO4_ABLATE"); a2.ablate = ab ? std::atoi(ab) : 0; }   // timing experiments only
+#endif
     static std::atomic<unsigned long long> attr_mask{0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
@@ -317,6 +400,21 @@ hipError_t launch_wino4_conv(ConvKind kind, const ConvArgs &a, hipStream_t st)
         if (e2 != hipSuccess) return e2;
         attr_mask.fetch_or(bit, std::memory_order_release);
     }
+#ifdef ADN_EXPERIMENTS
+    if (a2.ablate) {
+        const void *f = nullptr;
+        switch (a2.ablate) {
+#define W4_ABL(n) case n: f = reinterpret_cast<const void *>(wino4_conv_f32<CONV3X3_RELU, n>); break;
+            W4_ABL(1) W4_ABL(2) W4_ABL(4) W4_ABL(8) W4_ABL(16) W4_ABL(9) W4_ABL(18) W4_ABL(19) W4_ABL(27)
+#undef W4_ABL
+        default: return hipErrorInvalidValue;
+        }
+        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e != hipSuccess) return e;
+        void *args[] = {&a2};
+        return hipLaunchKernel(f, dim3((unsigned)nwg), dim3(NT), args, LDS_BYTES, st);
+    }
+#endif
     if (kind == CONV3X3_RELU_POOL)
         hipLaunchKernelGGL(wino4_conv_f32<CONV3X3_RELU_POOL>, dim3((unsigned)nwg), dim3(NT), LDS_BYTES, st, a2);
     else

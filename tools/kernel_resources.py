@@ -11,6 +11,8 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from audiodenoiser_amd.build import FILE_FLAGS  # noqa: E402
 
 
 def main():
@@ -18,7 +20,7 @@ def main():
     extra = sys.argv[2:]
     with tempfile.TemporaryDirectory() as d:
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", f"-I{ROOT}/include",
-               "-Rpass-analysis=kernel-resource-usage", src, "-o", os.path.join(d, "x.o")] + extra
+               "-Rpass-analysis=kernel-resource-usage", src, *FILE_FLAGS.get(os.path.basename(src), []), "-o", os.path.join(d, "x.o")] + extra
         r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stderr)
