@@ -484,7 +484,7 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
     } else if (fused_out)      // X = the buffer the fused layer wrote its partial planes to (the loop swapped X and Y)
         ADN_HIP(adn::launch_dot_finish(static_cast<const float *>(X), 2, h->out_b, y, (long)N * F * T, st));
     else
-        ADN_HIP(adn::launch_conv_out(X, f16, h->dev + h->out_w, h->out_b, y, (long)N * F * T, st));
+        ADN_HIP(adn::launch_conv_out(X, f16, h->dev + h->out_w, h->out_b, y, (long)N * F * T, (long)F * T, st));
     ADN_MARK();
     if (timed) {
         if (evi != ADN_N_LAUNCHES + 1) return fail(ADN_ERR_INVALID, "internal: launch count mismatch");

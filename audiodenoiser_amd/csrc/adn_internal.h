@@ -6,7 +6,22 @@
 
 namespace adn {
 
-// One NHWC activation source of a convolution (fp32 or fp16 storage, decided by the launcher).  (offY, offX) is
+// Activation layouts inside the library (never visible at the ABI: the network input and output have one channel).
+//   fp16: NHWC.
+//   fp32: channel-blocked "C8" = [N][C/8][H][W][8].  The 3x3 kernels walk K in chunks of 8 channels and copy a halo of
+//         neighbouring pixels per chunk: in C8 a halo row of one chunk is one contiguous run (34 pixels x 32 bytes), so
+//         the LDS-DMA gather fetches whole cache lines; in NHWC every 16-byte piece sat in a different 128-byte line of
+//         which a chunk used a quarter (measured on the F(4x4,3x3) kernel: the gather pattern alone cost 8 % of the
+//         batch-64 forward).  Every C is a multiple of 8 (64 ... 1024).
+// act_off: element offset of (pixel, channel) inside one image of C channels and HW pixels.
+template <typename T>
+__host__ __device__ __forceinline__ long act_off(int C, long HW, long pix, int c)
+{
+    if constexpr (sizeof(T) == 4) return ((long)(c >> 3) * HW + pix) * 8 + (c & 7);
+    else return pix * C + c;
+}
+
+// One activation source of a convolution (fp32 or fp16 storage, decided by the launcher).  (offY, offX) is
 // the zero-pad placed above / left of the tensor when it is aligned to the output domain (UpSampleLayer's F.pad,
 // reference model.py:44-47).
 struct ConvSrc {
@@ -88,7 +103,8 @@ hipError_t launch_conv_first(const float *x, const float *w9x64, const float *bi
 // y[i] = bias + sum over `planes` partial planes of CONV3X3_RELU_DOT (fixed order): the tail of the fused last layer.
 hipError_t launch_dot_finish(const float *planes, int nplanes, float bias, float *y, long npix, hipStream_t st);
 // Last layer: Conv2d(64 -> 1, 1x1), fp32 output.
-hipError_t launch_conv_out(const void *in, bool f16, const float *w64, float bias, float *out, long npix, hipStream_t st);
+hipError_t launch_conv_out(const void *in, bool f16, const float *w64, float bias, float *out, long npix, long HW,
+                           hipStream_t st);
 // NHWC -> NCHW fp32 (parity-test export only).
 hipError_t launch_nhwc_to_nchw(const void *in, bool f16, float *out, int N, int H, int W, int C, hipStream_t st);
 

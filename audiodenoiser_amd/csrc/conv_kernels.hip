@@ -4,8 +4,9 @@
 // (/root/reference/code/model.py:7-50): conv3x3+BatchNorm+ReLU, MaxPool2d(2), ConvTranspose2d(2,2),
 // F.pad + torch.cat, and the first (Cin=1) and last (1x1, Cout=1) convolutions (model.py:56,68).
 //
-// Layout: activations are NHWC inside the library (Cin = 1 at the entry and Cout = 1 at the exit make
-// NCHW == NHWC at the API boundary, so no transpose is ever materialised).  Every kernel is templated on the
+// Layout: activations are NHWC (fp16) or channel-blocked [N][C/8][H][W][8] (fp32; see adn_internal.h) inside the
+// library (Cin = 1 at the entry and Cout = 1 at the exit make every layout identical at the API boundary, so no
+// transpose is ever materialised).  Every kernel is templated on the
 // storage type T: float (exact-fp32 path) or _Float16 (fp16 storage, fp16 MFMA with fp32 accumulation —
 // BASELINE configs[4]).
 //
@@ -70,6 +71,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &p, f32x16 (&acc)[T
     // row m of m-block i -> tile pixel (trow, tcol) = ((wm*MB+i)*2 + (m>>4), m&15).
     T *outp = static_cast<T *>(p.out);
     T *poolp = static_cast<T *>(p.pool);
+    const int ps = sizeof(T) == 4 ? 8 : p.Cout;                 // elements between neighbouring pixels (C8 / NHWC, adn_internal.h)
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         const int col = ct * BN + (wn * NB + j) * 32 + l31;     // GEMM column
@@ -81,30 +83,30 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &p, f32x16 (&acc)[T
                 // column = (di*2+dj)*Cout + co ; output pixel (2*gy+di, 2*gx+dj); bias only, no activation.
                 const int ij = col / p.Cout, co = col - ij * p.Cout;
                 const int Ho = 2 * p.H, Wo = 2 * p.W;
-                T *ob = outp + (size_t)n * Ho * Wo * p.Cout + co;
+                T *ob = outp + (size_t)n * Ho * Wo * p.Cout + act_off<T>(p.Cout, (long)Ho * Wo, 0, co);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = (r & 3) + 8 * (r >> 2) + 4 * hh;
                     const int gy = ty * TH + trow0 + (m >> 4), gx = tx * TW + (m & 15);
                     if (gy < p.H && gx < p.W)
-                        ob[((size_t)(2 * gy + (ij >> 1)) * Wo + (2 * gx + (ij & 1))) * p.Cout] = (T)(acc[i][j][r] + bv);
+                        ob[((size_t)(2 * gy + (ij >> 1)) * Wo + (2 * gx + (ij & 1))) * ps] = (T)(acc[i][j][r] + bv);
                 }
             } else {
                 float v[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc[i][j][r] + bv, 0.f);
-                T *ob = outp + (size_t)n * p.H * p.W * p.Cout + col;
+                T *ob = outp + (size_t)n * p.H * p.W * p.Cout + act_off<T>(p.Cout, (long)p.H * p.W, 0, col);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = (r & 3) + 8 * (r >> 2) + 4 * hh;
                     const int gy = ty * TH + trow0 + (m >> 4), gx = tx * TW + (m & 15);
-                    if (gy < p.H && gx < p.W) ob[((size_t)gy * p.W + gx) * p.Cout] = (T)v[r];
+                    if (gy < p.H && gx < p.W) ob[((size_t)gy * p.W + gx) * ps] = (T)v[r];
                 }
                 if (EPI == CONV3X3_RELU_POOL) {
                     // 2x2 window (rows trow0, trow0+1; cols tcol, tcol+1 with tcol even) = registers
                     // (q,pp), (q,pp+1), (q+2,pp), (q+2,pp+1) with r = 4q+pp, q in {0,1}, pp in {0,2}.
                     const int Hp = p.H >> 1, Wp = p.W >> 1;
-                    T *pb = poolp + (size_t)n * Hp * Wp * p.Cout + col;
+                    T *pb = poolp + (size_t)n * Hp * Wp * p.Cout + act_off<T>(p.Cout, (long)Hp * Wp, 0, col);
                     const int py = (ty * TH + trow0) >> 1;
 #pragma unroll
                     for (int q = 0; q < 2; ++q)
@@ -113,7 +115,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &p, f32x16 (&acc)[T
                             const float m4 = fmaxf(fmaxf(v[4 * q + pp], v[4 * q + pp + 1]),
                                                    fmaxf(v[4 * (q + 2) + pp], v[4 * (q + 2) + pp + 1]));
                             const int px = ((tx * TW) >> 1) + (pp >> 1) + 2 * hh + 4 * q;
-                            if (py < Hp && px < Wp) pb[((size_t)py * Wp + px) * p.Cout] = (T)m4;
+                            if (py < Hp && px < Wp) pb[((size_t)py * Wp + px) * ps] = (T)m4;
                         }
                 }
             }
@@ -176,13 +178,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 4) void conv_mfm
         alds[r] = in_range ? pix * ASTR + q * 4 : -1;
         const int y0 = gy - p.s0.offY, x0 = gx - p.s0.offX;
         hcur[r] = (in_range && y0 >= 0 && y0 < p.s0.H && x0 >= 0 && x0 < p.s0.W)
-                      ? (y0 * p.s0.W + x0) * p.s0.C + q * EPV : -1;
+                      ? (int)act_off<T>(p.s0.C, (long)p.s0.H * p.s0.W, y0 * p.s0.W + x0, q * EPV) : -1;
         const int y1 = gy - p.s1.offY, x1 = gx - p.s1.offX;
         hsec[r] = (in_range && y1 >= 0 && y1 < p.s1.H && x1 >= 0 && x1 < p.s1.W)
-                      ? (y1 * p.s1.W + x1) * p.s1.C + q * EPV : -1;
+                      ? (int)act_off<T>(p.s1.C, (long)p.s1.H * p.s1.W, y1 * p.s1.W + x1, q * EPV) : -1;
     }
     const T *srcp = static_cast<const T *>(p.s0.ptr) + (size_t)n * p.s0.H * p.s0.W * p.s0.C;
     const T *base1 = static_cast<const T *>(p.s1.ptr) + (size_t)n * p.s1.H * p.s1.W * p.s1.C;
+    // elements from one K-chunk to the next in the current source: KC channels (NHWC) or KG 8-channel blocks (C8)
+    size_t cstr = sizeof(T) == 4 ? (size_t)KG * p.s0.H * p.s0.W * 8 : (size_t)KC;
+    const size_t cstr1 = sizeof(T) == 4 ? (size_t)KG * p.s1.H * p.s1.W * 8 : (size_t)KC;
     const float *wp = static_cast<const float *>(p.wpk) + (size_t)ct * p.nchunk * B_DW;
 
     f32x4 ra[A_ROUNDS], rb[B_ROUNDS];
@@ -191,6 +196,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 4) void conv_mfm
     do {                                                                                       \
         if ((c) == p.nchunk0) {                       /* wave-uniform: switch to the second source */ \
             srcp = base1;                                                                      \
+            cstr = cstr1;                                                                      \
             _Pragma("unroll") for (int r = 0; r < A_ROUNDS; ++r) hcur[r] = hsec[r];            \
         }                                                                                      \
         _Pragma("unroll") for (int r = 0; r < A_ROUNDS; ++r) {                                 \
@@ -205,7 +211,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 4) void conv_mfm
             const int citem_ = (B_ITEMS % NTHREADS == 0 || item_ < B_ITEMS) ? item_ : 0;       \
             rb[r] = *reinterpret_cast<const f32x4 *>(wp + citem_ * 4);                         \
         }                                                                                      \
-        srcp += KC;                                                                            \
+        srcp += cstr;                                                                          \
         wp += B_DW;                                                                            \
     } while (0)
 
@@ -499,12 +505,17 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void conv_dma(const ConvArgs p)
         const bool data = s < C::A_USED && pix < PW && q < C::KQ;
         const int gy = gy0 + row, gx = gx0 + pix;
         const int y0 = gy - p.s0.offY, x0 = gx - p.s0.offX;
-        hcur[r] = (data && y0 >= 0 && y0 < p.s0.H && x0 >= 0 && x0 < p.s0.W) ? (y0 * p.s0.W + x0) * p.s0.C + q * EPV : -1;
+        hcur[r] = (data && y0 >= 0 && y0 < p.s0.H && x0 >= 0 && x0 < p.s0.W)
+                      ? (int)act_off<T>(p.s0.C, (long)p.s0.H * p.s0.W, y0 * p.s0.W + x0, q * EPV) : -1;
         const int y1 = gy - p.s1.offY, x1 = gx - p.s1.offX;
-        hsec[r] = (data && y1 >= 0 && y1 < p.s1.H && x1 >= 0 && x1 < p.s1.W) ? (y1 * p.s1.W + x1) * p.s1.C + q * EPV : -1;
+        hsec[r] = (data && y1 >= 0 && y1 < p.s1.H && x1 >= 0 && x1 < p.s1.W)
+                      ? (int)act_off<T>(p.s1.C, (long)p.s1.H * p.s1.W, y1 * p.s1.W + x1, q * EPV) : -1;
     }
     const T *srcp = static_cast<const T *>(p.s0.ptr) + (size_t)n * p.s0.H * p.s0.W * p.s0.C;   // next chunk's channels
     const T *base1 = static_cast<const T *>(p.s1.ptr) + (size_t)n * p.s1.H * p.s1.W * p.s1.C;
+    // elements from one K-chunk to the next in the current source: KC channels (NHWC) or KG 8-channel blocks (C8)
+    size_t cstr = sizeof(T) == 4 ? (size_t)KG * p.s0.H * p.s0.W * 8 : (size_t)KC;
+    const size_t cstr1 = sizeof(T) == 4 ? (size_t)KG * p.s1.H * p.s1.W * 8 : (size_t)KC;
     const float *wp = static_cast<const float *>(p.wpk) + (size_t)ct * p.nchunk * B_DW;            // next chunk's slab
     const float *zsrc = p.zeros;
 
@@ -512,6 +523,7 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void conv_dma(const ConvArgs p)
     auto dma_chunk = [&](int c, int buf) {
         if (c == p.nchunk0) {                          // wave-uniform: switch to the second source (virtual concat)
             srcp = base1;
+            cstr = cstr1;
 #pragma unroll
             for (int r = 0; r < A_ROUNDS; ++r) hcur[r] = hsec[r];
         }
@@ -528,7 +540,7 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void conv_dma(const ConvArgs p)
                 conv_dma16(wp + (size_t)(sb - A_SLOTS + lane) * 4, dst);
             }
         }
-        srcp += KC;
+        srcp += cstr;
         wp += B_DW;
     };
 
@@ -640,7 +652,9 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
             for (int j = 0; j < FIRST_PX + 2; ++j) v[dy][j] = s_win[(r + dy) * WP + min(x0 + j, WP - 1)];
-        T *op = out + (((long)n * H + y0 + r) * W + x0) * 64 + q * 4;
+        // lane q owns couts 4q .. 4q+3 of 64: NHWC (fp16) or block q/2, floats 4(q&1).. of the C8 layout (fp32)
+        T *op = out + (long)n * H * W * 64 + act_off<T>(64, (long)H * W, (long)(y0 + r) * W + x0, q * 4);
+        constexpr int ps = sizeof(T) == 4 ? 8 : 64;            // elements between neighbouring pixels
 #pragma unroll
         for (int px = 0; px < FIRST_PX; ++px) {
             f32x4 a = bv;
@@ -651,9 +665,9 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict
             a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
             if (x0 + px < W) {
                 if constexpr (sizeof(T) == 4) {
-                    *reinterpret_cast<f32x4 *>(op + px * 64) = a;
+                    *reinterpret_cast<f32x4 *>(op + px * ps) = a;
                 } else {
-                    *reinterpret_cast<f16x4 *>(op + px * 64) =
+                    *reinterpret_cast<f16x4 *>(op + px * ps) =
                         f16x4{(_Float16)a.x, (_Float16)a.y, (_Float16)a.z, (_Float16)a.w};
                 }
             }
@@ -665,7 +679,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict
 // 4-step xor-shuffle reduction inside the 16-lane group.  Output is always fp32.
 template <typename T>
 __global__ __launch_bounds__(256) void conv_out_kernel(const T *__restrict__ in, const float *__restrict__ w64,
-                                                       float bias, float *__restrict__ out, long npix)
+                                                       float bias, float *__restrict__ out, long npix, long HW)
 {
     const int q = threadIdx.x & 15;
     const int slot = threadIdx.x >> 4;
@@ -677,7 +691,8 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const T *__restrict__ in,
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (pix < npix) {
             if constexpr (sizeof(T) == 4) {
-                v = *reinterpret_cast<const f32x4 *>(in + pix * 64 + q * 4);
+                const long img = pix / HW;                             // C8: 8 blocks of HW pixels x 8 channels per image
+                v = *reinterpret_cast<const f32x4 *>(in + img * HW * 64 + act_off<float>(64, HW, pix - img * HW, q * 4));
             } else {
                 const f16x4 hv = *reinterpret_cast<const f16x4 *>(in + pix * 64 + q * 4);
                 v = f32x4{(float)hv.x, (float)hv.y, (float)hv.z, (float)hv.w};
@@ -705,7 +720,7 @@ __global__ __launch_bounds__(256) void dot_finish_kernel(const float *__restrict
     }
 }
 
-// NHWC (T) -> NCHW (fp32) through a 32x33 LDS tile (parity-test export only).
+// internal layout (NHWC fp16 / C8 fp32, adn_internal.h) -> NCHW fp32 through a 32x33 LDS tile (parity-test export only).
 template <typename T>
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T *__restrict__ in, float *__restrict__ out,
                                                            long HW, int C)
@@ -718,7 +733,7 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T *__restrict__
     for (int k = ty; k < 32; k += 8) {
         const long pp = p0 + k;
         const int c = c0 + tx;
-        tile[k][tx] = (pp < HW && c < C) ? (float)in[(n * HW + pp) * C + c] : 0.f;
+        tile[k][tx] = (pp < HW && c < C) ? (float)in[n * HW * C + act_off<T>(C, HW, pp, c)] : 0.f;
     }
     __syncthreads();
     for (int k = ty; k < 32; k += 8) {
@@ -851,16 +866,18 @@ hipError_t launch_conv_first(const float *x, const float *w9x64, const float *bi
     return hipGetLastError();
 }
 
-hipError_t launch_conv_out(const void *in, bool f16, const float *w64, float bias, float *out, long npix, hipStream_t st)
+hipError_t launch_conv_out(const void *in, bool f16, const float *w64, float bias, float *out, long npix, long HW,
+                           hipStream_t st)
 {
+    if (HW <= 0 || npix % HW) return hipErrorInvalidValue;
     long blocks = (npix + 15) / 16;
     if (blocks > 256L * 32) blocks = 256L * 32;
     if (f16)
         hipLaunchKernelGGL(conv_out_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), 0, st,
-                           static_cast<const _Float16 *>(in), w64, bias, out, npix);
+                           static_cast<const _Float16 *>(in), w64, bias, out, npix, HW);
     else
         hipLaunchKernelGGL(conv_out_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st,
-                           static_cast<const float *>(in), w64, bias, out, npix);
+                           static_cast<const float *>(in), w64, bias, out, npix, HW);
     return hipGetLastError();
 }
 

@@ -2,7 +2,7 @@
 //
 // Same role as wino_conv_dma_f32 (wino_kernels.hip) for the 3x3 layers of the reference's DoubleConvLayer
 // (/root/reference/code/model.py:7-20): conv3x3(pad 1) + folded BatchNorm + ReLU (+ MaxPool2d(2), + virtual
-// F.pad/torch.cat of the up path), NHWC fp32 in and out.  F(4x4,3x3) needs 36 multiplies per 4x4 output tile and
+// F.pad/torch.cat of the up path), channel-blocked fp32 in and out (C8, adn_internal.h).  F(4x4,3x3) needs 36 multiplies per 4x4 output tile and
 // input channel instead of 144: 4x fewer matrix-core FLOPs than the direct form, 1.78x fewer than F(2x2,3x3):
 //      Y = A^T [ (G g G^T) .* (B^T d B) ] A        summed over input channels, interpolation points 0, +-1, +-2, inf
 //   U = G g G^T (6x6) is precomputed on the host in double precision (BatchNorm scale folded in);
@@ -104,7 +104,8 @@ __device__ __forceinline__ void at6(float m0, float m1, float m2, float m3, floa
 }
 
 // ABL: timing experiments (-DADN_EXPERIMENTS builds, ADN_WINO4_ABLATE): 1 no copies after the first chunk, 2 no patch
-// reads / transform, 4 no transform, 8 no barrier, 16 no B-fragment reads; results are wrong by design.  0 in production.
+// reads / transform, 4 no transform, 8 no barrier, 16 no B-fragment reads, 32 no U copies, 64 no halo copies, 128 every
+// copy reads the zero block; results are wrong by design.  0 in production.
 template <int EPI, int ABL = 0>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino4_conv_f32(const ConvArgs p)
 {
@@ -155,17 +156,19 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             const int c = jj - half * HP;
             const bool data = row < HP && jj >= 0 && jj < 2 * HP;
             const int y = gy0 + row - s.offY, x = gx0 + c - s.offX;
-            hcur[r] = (data && y >= 0 && y < s.H && x >= 0 && x < s.W) ? (y * s.W + x) * s.C + half * 4 : -1;
+            hcur[r] = (data && y >= 0 && y < s.H && x >= 0 && x < s.W) ? (y * s.W + x) * 8 + half * 4 : -1;   // C8 layout
         }
     };
     plan(p.s0);
-    const float *srcp = static_cast<const float *>(p.s0.ptr) + (size_t)n * p.s0.H * p.s0.W * p.s0.C;
+    const float *srcp = static_cast<const float *>(p.s0.ptr) + (size_t)n * p.s0.H * p.s0.W * p.s0.C;   // next chunk's 8-channel block
+    size_t cstr = (size_t)p.s0.H * p.s0.W * 8;         // floats between consecutive channel blocks of the current source
     const float *zsrc = p.zeros;
 
 #define W4_DMA_BEGIN(c)                                                                        \
     do {                                                                                       \
         if ((c) == p.nchunk0) {                       /* wave-uniform: switch to the second source (virtual concat) */ \
             srcp = static_cast<const float *>(p.s1.ptr) + (size_t)n * p.s1.H * p.s1.W * p.s1.C; \
+            cstr = (size_t)p.s1.H * p.s1.W * 8;                                                \
             plan(p.s1);                                                                        \
         }                                                                                      \
     } while (0)
@@ -173,12 +176,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #define W4_DMA_PIECE(k, buf)                                                                   \
     do {                                                                                       \
         float *dst_ = smem + (buf) * IMG + ((k) * NT + wave * 64) * 4;                         \
-        if ((k) < HR) dma16(hcur[(k) < HR ? (k) : 0] >= 0 ? srcp + hcur[(k) < HR ? (k) : 0] : zsrc, dst_); \
-        else if (((k) - HR) * NT + wave * 64 < USLOTS) dma16(wp + ((k) - HR) * NT * 4, dst_);  \
+        if ((k) < HR) {                                                                        \
+            if (ABL & 256) dma16(srcp + (((k) * NT + tid) * 4) % 8192, dst_);          /* contiguous stand-in for the halo gather */ \
+            else if (!(ABL & 64)) dma16((hcur[(k) < HR ? (k) : 0] >= 0 && !(ABL & 128)) ? srcp + hcur[(k) < HR ? (k) : 0] : zsrc, dst_); \
+        } else if (((k) - HR) * NT + wave * 64 < USLOTS && !(ABL & 32))                        \
+            dma16((ABL & 128) ? zsrc : wp + ((k) - HR) * NT * 4, dst_);                        \
     } while (0)
 #define W4_DMA_END()                                                                           \
     do {                                                                                       \
-        srcp += KC;                                                                            \
+        srcp += cstr;                                                                          \
         wp += USLOTS * 4;                                                                      \
     } while (0)
 
@@ -330,8 +336,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const float *xr = smem + ((tb * 2 + (jh ^ 1)) * 16 * 64 + lane) * 4;  // the partner's block: its sum for OUR cout block
     const int Hp = p.H >> 1, Wp = p.W >> 1;
     const int col = ct * 32 + 16 * jh + ti;
-    float *ob = static_cast<float *>(p.out) + (size_t)n * p.H * p.W * p.Cout + col;
-    float *pb = (EPI == CONV3X3_RELU_POOL) ? static_cast<float *>(p.pool) + (size_t)n * Hp * Wp * p.Cout + col : nullptr;
+    float *ob = static_cast<float *>(p.out) + (size_t)n * p.H * p.W * p.Cout + act_off<float>(p.Cout, (long)p.H * p.W, 0, col);
+    float *pb = (EPI == CONV3X3_RELU_POOL)
+                    ? static_cast<float *>(p.pool) + (size_t)n * Hp * Wp * p.Cout + act_off<float>(p.Cout, (long)Hp * Wp, 0, col)
+                    : nullptr;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         float y[4][4];
@@ -343,7 +351,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 y[a][b] = fmaxf(y[a][b] + o[b] + bias_r, 0.f);
-                if (gy + a < p.H && gx + b < p.W) ob[((size_t)(gy + a) * p.W + gx + b) * p.Cout] = y[a][b];
+                if (gy + a < p.H && gx + b < p.W) ob[((size_t)(gy + a) * p.W + gx + b) * 8] = y[a][b];
             }
         }
         if (EPI == CONV3X3_RELU_POOL) {
@@ -353,7 +361,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 for (int b = 0; b < 2; ++b) {
                     const float mx = fmaxf(fmaxf(y[2 * a][2 * b], y[2 * a][2 * b + 1]), fmaxf(y[2 * a + 1][2 * b], y[2 * a + 1][2 * b + 1]));
                     const int py = (gy >> 1) + a, px = (gx >> 1) + b;
-                    if (py < Hp && px < Wp) pb[((size_t)py * Wp + px) * p.Cout] = mx;
+                    if (py < Hp && px < Wp) pb[((size_t)py * Wp + px) * 8] = mx;
                 }
         }
     }
@@ -405,7 +413,8 @@ hipError_t launch_wino4_conv(ConvKind kind, const ConvArgs &a, hipStream_t st)
         const void *f = nullptr;
         switch (a2.ablate) {
 #define W4_ABL(n) case n: f = reinterpret_cast<const void *>(wino4_conv_f32<CONV3X3_RELU, n>); break;
-            W4_ABL(1) W4_ABL(2) W4_ABL(4) W4_ABL(8) W4_ABL(16) W4_ABL(9) W4_ABL(18) W4_ABL(19) W4_ABL(27)
+            W4_ABL(1) W4_ABL(2) W4_ABL(4) W4_ABL(8) W4_ABL(16) W4_ABL(9) W4_ABL(18) W4_ABL(19) W4_ABL(27) W4_ABL(32) W4_ABL(64)
+            W4_ABL(128) W4_ABL(256)
 #undef W4_ABL
         default: return hipErrorInvalidValue;
         }

@@ -2,7 +2,7 @@
 //
 // Same role as conv_mfma_f32 (conv_kernels.hip) for the 3x3 layers of the reference's DoubleConvLayer
 // (/root/reference/code/model.py:7-20): conv3x3(pad 1) + folded BatchNorm + ReLU (+ MaxPool2d(2), + virtual
-// F.pad/torch.cat of the up path), NHWC fp32 in and out.  The minimal-filtering algorithm needs 16 multiplies
+// F.pad/torch.cat of the up path), channel-blocked fp32 in and out (C8, adn_internal.h).  The minimal-filtering algorithm needs 16 multiplies
 // per 2x2 output tile and input channel instead of 36, i.e. 2.25x fewer matrix-core FLOPs, and stays in exact
 // fp32 (transforms are additions and multiplications by 1/2):
 //      Y = A^T [ (G g G^T) .* (B^T d B) ] A        summed over input channels
@@ -152,9 +152,9 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
         const bool data = s < G::HUSED && !(NW == 4 && k == 16) && pix < G::HW;
         const int gy = gy0 + row, gx = gx0 + pix;
         const int y0 = gy - p.s0.offY, x0 = gx - p.s0.offX;
-        hcur[r] = (data && y0 >= 0 && y0 < p.s0.H && x0 >= 0 && x0 < p.s0.W) ? (y0 * p.s0.W + x0) * p.s0.C + part * 4 : -1;
+        hcur[r] = (data && y0 >= 0 && y0 < p.s0.H && x0 >= 0 && x0 < p.s0.W) ? (y0 * p.s0.W + x0) * 8 + part * 4 : -1;   // C8 layout
         const int y1 = gy - p.s1.offY, x1 = gx - p.s1.offX;
-        hsec[r] = (data && y1 >= 0 && y1 < p.s1.H && x1 >= 0 && x1 < p.s1.W) ? (y1 * p.s1.W + x1) * p.s1.C + part * 4 : -1;
+        hsec[r] = (data && y1 >= 0 && y1 < p.s1.H && x1 >= 0 && x1 < p.s1.W) ? (y1 * p.s1.W + x1) * 8 + part * 4 : -1;
     }
     if constexpr (SRC == 1) {
         // plan of the fused first layer: hcur = index of the slot's 3x3 input window in the LDS copy (-1: the halo pixel
@@ -175,13 +175,17 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
     float *const sW = sX + XWIN;
     const float *srcp = static_cast<const float *>(p.s0.ptr) + (size_t)n * p.s0.H * p.s0.W * p.s0.C;   // next chunk's channels
     const float *base1 = static_cast<const float *>(p.s1.ptr) + (size_t)n * p.s1.H * p.s1.W * p.s1.C;
+    // floats between consecutive 8-channel blocks (= K-chunks) of the current source (C8 layout, adn_internal.h)
+    size_t cstr = (size_t)p.s0.H * p.s0.W * 8;
+    const size_t cstr1 = (size_t)p.s1.H * p.s1.W * 8;
     if (SPLIT) {
         if (c0 >= p.nchunk0) {                            // the slice starts inside the second source (virtual concat)
-            srcp = base1 + (size_t)(c0 - p.nchunk0) * WKC;
+            srcp = base1 + (size_t)(c0 - p.nchunk0) * cstr1;
+            cstr = cstr1;
 #pragma unroll
             for (int r = 0; r < HR; ++r) hcur[r] = hsec[r];
         } else {
-            srcp += (size_t)c0 * WKC;
+            srcp += (size_t)c0 * cstr;
         }
     }
     const float *zsrc = p.zeros;
@@ -211,6 +215,7 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
         if constexpr (SRC == 0) {                                                              \
         if ((c) == p.nchunk0) {                       /* wave-uniform: switch to the second source */ \
             srcp = base1;                                                                      \
+            cstr = cstr1;                                                                      \
             _Pragma("unroll") for (int r = 0; r < HR; ++r) hcur[r] = hsec[r];                  \
         }                                                                                      \
         }                                                                                      \
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
     } while (0)
 #define ADN_DMA_END()                                                                          \
     do {                                                                                       \
-        srcp += WKC;                                                                           \
+        srcp += cstr;                                                                          \
         wp += 4096;                                                                            \
         ++fchunk;                                                                              \
     } while (0)
@@ -461,8 +466,10 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
     for (int j = 0; j < 2; ++j) {
         const int col = ct * WBN + 16 * j + ti;
         const float bv = bias_r[j];
-        float *ob = static_cast<float *>(p.out) + (size_t)n * p.H * p.W * p.Cout + col;
-        float *pb = (EPI == CONV3X3_RELU_POOL) ? static_cast<float *>(p.pool) + (size_t)n * Hp * Wp * p.Cout + col : nullptr;
+        float *ob = static_cast<float *>(p.out) + (size_t)n * p.H * p.W * p.Cout + act_off<float>(p.Cout, (long)p.H * p.W, 0, col);
+        float *pb = (EPI == CONV3X3_RELU_POOL)
+                        ? static_cast<float *>(p.pool) + (size_t)n * Hp * Wp * p.Cout + act_off<float>(p.Cout, (long)Hp * Wp, 0, col)
+                        : nullptr;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int tile = 4 * q + r;
@@ -495,11 +502,11 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
                 for (int b = 0; b < 2; ++b) {
                     const float v = fmaxf(y[a][b] + bv, 0.f);
                     mx = fmaxf(mx, v);
-                    if (gy + a < p.H && gx + b < p.W) ob[((size_t)(gy + a) * p.W + gx + b) * p.Cout] = v;
+                    if (gy + a < p.H && gx + b < p.W) ob[((size_t)(gy + a) * p.W + gx + b) * 8] = v;
                 }
             if (EPI == CONV3X3_RELU_POOL) {
                 const int py = gy >> 1, px = gx >> 1;
-                if (py < Hp && px < Wp) pb[((size_t)py * Wp + px) * p.Cout] = mx;
+                if (py < Hp && px < Wp) pb[((size_t)py * Wp + px) * 8] = mx;
             }
         }
     }
@@ -530,16 +537,17 @@ __global__ __launch_bounds__(256) void wino_reduce_kernel(const float *__restric
         for (int b = 0; b < 2; ++b) {
             const int gy = 2 * by + a, gx = 2 * bx + b;
             if (gy >= H || gx >= W) continue;
-            const size_t o = (size_t)n * img + ((size_t)gy * W + gx) * Cout + c4;
+            const size_t o = (size_t)n * img + ((size_t)gy * W + gx) * Cout + c4;      // partial sums: pixel-major
             f32x4 v = *reinterpret_cast<const f32x4 *>(partial + o);
             for (int s = 1; s < ksplit; ++s) v += *reinterpret_cast<const f32x4 *>(partial + s * split_stride + o);
             v += bv;
             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-            *reinterpret_cast<f32x4 *>(out + o) = v;
+            *reinterpret_cast<f32x4 *>(out + (size_t)n * img + act_off<float>(Cout, (long)H * W, (long)gy * W + gx, c4)) = v;   // C8
             mx.x = fmaxf(mx.x, v.x); mx.y = fmaxf(mx.y, v.y); mx.z = fmaxf(mx.z, v.z); mx.w = fmaxf(mx.w, v.w);
         }
     if (EPI == CONV3X3_RELU_POOL && by < H / 2 && bx < W / 2)
-        *reinterpret_cast<f32x4 *>(pool + (((size_t)n * (H / 2) + by) * (W / 2) + bx) * Cout + c4) = mx;
+        *reinterpret_cast<f32x4 *>(pool + (size_t)n * (H / 2) * (W / 2) * Cout +
+                                   act_off<float>(Cout, (long)(H / 2) * (W / 2), (long)by * (W / 2) + bx, c4)) = mx;
 }
 
 template <int NW>

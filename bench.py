@@ -312,6 +312,8 @@ def main() -> None:
     ap.add_argument("--stft-steps", type=int, default=20)
     ap.add_argument("--f16-steps", type=int, default=10)
     ap.add_argument("--no-stft-cpu", action="store_true", help="skip the C-oracle STFT timing inside the stft sub-benchmark")
+    ap.add_argument("--no-finite-check", action="store_true",
+                    help="timing experiments of an ADN_BUILD_EXPERIMENTS library only (ablated kernels produce garbage)")
     ap.add_argument("--dtype", choices=("f32", "f16"), default="f32",
                     help="f32 = headline metric (default); f16 = run the MAIN loop on the fp16 path (BASELINE configs[4])")
     args = ap.parse_args()
@@ -360,7 +362,7 @@ def main() -> None:
         D.barrier()
         elapsed = time.perf_counter() - t0
     elapsed = D.max_over_ranks(elapsed, dev)
-    assert allv.numel() == 4 * b * world and bool(torch.isfinite(allv).all())
+    assert allv.numel() == 4 * b * world and (args.no_finite_check or bool(torch.isfinite(allv).all()))
     ms_mean = launch_timings(net, args.steps)      # per-launch durations of the timed steps (events inside libadn)
 
     if rank == 0:

@@ -8,7 +8,7 @@ mkdir -p gpurun_out
 out=gpurun_out/wino4_ablate.txt
 : > $out
 for ab in ${@:-0 1 2 4 8 16 9 18 19 27}; do
-    ADN_WINO4_ABLATE=$ab python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras 2>gpurun_out/wino4_ablate.err | python -c "
+    ADN_WINO4_ABLATE=$ab python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-finite-check 2>gpurun_out/wino4_ablate.err | python -c "
 import json, sys
 d = json.loads(sys.stdin.read())
 t = d['forward']['per_launch_ms']
