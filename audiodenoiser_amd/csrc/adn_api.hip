@@ -358,13 +358,17 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
     // Winograd path: the first convolution (Cin = 1) is fused into down1's second one -- its 64-channel result is computed
     // tile by tile inside that kernel and never written (timing slot 0 stays empty).
     bool fused_first = h->use_wino;
-    if (fused_first && h->allow_split) {
-        // split-K (opt-in, small batches) may cut down1's second conv along K: the fused form has no split variant
+    if (fused_first) {
         adn::ConvArgs probe{};
         probe.N = N; probe.H = p.H[0]; probe.W = p.W[0];
+        probe.Cout = 64; probe.nchunk = 64 / 8; probe.ksplit = 1;
+        // where the F(4x4,3x3) kernel takes down1's second conv the first layer runs as its own launch (the fused form is
+        // time-neutral on F(2x2,3x3); unfused + F(4x4,3x3) is 1.1 ms faster at batch 64)
+        if (h->use_wino4 && adn::wino4_applicable(adn::CONV3X3_RELU_POOL, probe, h->force_wino4)) fused_first = false;
+        // split-K (opt-in, small batches) may cut down1's second conv along K: the fused form has no split variant
         probe.tilesY = (p.H[0] + 15) / 16;
         probe.nct = 64 / h->wino_bn;
-        if (adn::wino_ksplit(adn::wino_workgroups(probe), 64 / 8) > 1) fused_first = false;
+        if (h->allow_split && adn::wino_ksplit(adn::wino_workgroups(probe), 64 / 8) > 1) fused_first = false;
     }
     ADN_MARK();
     if (!fused_first)
@@ -456,7 +460,9 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
         // instead).  Not when block outputs are exported (the up4 tap IS that tensor).
         // fp16 path: a workgroup of conv_dma holds all 64 channels, the dot is finished in its epilogue (writes y).
         const bool fuse_f16 = l == 0 && f16 && !taps && b.nct == 1;
-        fused_out = l == 0 && h->use_wino && !taps && b.nct == 2;
+        // (where the F(4x4,3x3) kernel applies it takes this layer unfused: faster than the fused F(2x2,3x3) form)
+        fused_out = l == 0 && h->use_wino && !taps && b.nct == 2 &&
+                    !(b.wpk4 && adn::wino4_applicable(adn::CONV3X3_RELU, b, h->force_wino4));
         if (fused_out) {
             b.dotw = h->dev + h->out_w;
             b.dot_out = static_cast<float *>(Y);

@@ -370,7 +370,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 }  // namespace
 
 // F(4x4,3x3) serves a layer when its 32x32-pixel workgroup tiles waste little of the image: at most a quarter of the
-// tiled area outside the image (the 32x16 bottleneck and small images stay on F(2x2,3x3), whose tiles are 16x16).
+// tiled area outside it (the 32x16 bottleneck and small images stay on F(2x2,3x3), whose tiles are 16x16).  The choice
+// depends on the layer's geometry only, never on the batch: a clip's result is bit-identical whatever batch it is
+// computed in.  (Serving single clips: ADN_WINO_TILE=2 keeps the finer F(2x2,3x3) grid, which fills the chip better.)
 // force: every plain / pooled layer whatever its size (ADN_WINO_TILE=4; parity tests of the tile-edge handling).
 bool wino4_applicable(ConvKind kind, const ConvArgs &a, bool force)
 {
