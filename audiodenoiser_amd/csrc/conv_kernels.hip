@@ -675,6 +675,51 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict
     }
 }
 
+// The same layer for the channel-blocked fp32 layout (C8, adn_internal.h): one thread = one pixel, all 64 output channels
+// block by block.  The 9 x 8 weights of a block are wave-uniform (scalar loads, used as scalar operands of the FMAs), the
+// pixel's 3x3 window is read from LDS once for all blocks, and a wave's two 16-byte stores per block cover 64 neighbouring
+// pixels x 32 bytes = 2 KB contiguous.
+__global__ __launch_bounds__(256) void conv_first_c8_kernel(const float *__restrict__ x, const float *__restrict__ w9x64,
+                                                            const float *__restrict__ bias, float *__restrict__ out,
+                                                            int H, int W, int tiles_per_img)
+{
+    extern __shared__ float s_win[];               // (FIRST_ROWS+2) rows x (W+2), zero halo
+    const int n = blockIdx.x / tiles_per_img;
+    const int y0 = (blockIdx.x - n * tiles_per_img) * FIRST_ROWS;
+    const int WP = W + 2;
+    const float *xp = x + (long)n * H * W;
+    for (int i = threadIdx.x; i < (FIRST_ROWS + 2) * WP; i += 256) {
+        const int r = i / WP, c = i - r * WP;
+        const int yy = y0 + r - 1, xx = c - 1;
+        s_win[i] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? xp[(long)yy * W + xx] : 0.f;
+    }
+    __syncthreads();
+    const int rows = min(FIRST_ROWS, H - y0);
+    const size_t bstr = (size_t)H * W * 8;         // floats between channel blocks
+    for (int i = threadIdx.x; i < rows * W; i += 256) {
+        const int r = i / W, xx = i - r * W;
+        float v[9];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) v[dy * 3 + dx] = s_win[(r + dy) * WP + xx + dx];
+        float *op = out + (size_t)n * H * W * 64 + ((size_t)(y0 + r) * W + xx) * 8;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            f32x4 a0 = *reinterpret_cast<const f32x4 *>(bias + b * 8), a1 = *reinterpret_cast<const f32x4 *>(bias + b * 8 + 4);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                a0 += *reinterpret_cast<const f32x4 *>(w9x64 + t * 64 + b * 8) * v[t];
+                a1 += *reinterpret_cast<const f32x4 *>(w9x64 + t * 64 + b * 8 + 4) * v[t];
+            }
+            a0.x = fmaxf(a0.x, 0.f); a0.y = fmaxf(a0.y, 0.f); a0.z = fmaxf(a0.z, 0.f); a0.w = fmaxf(a0.w, 0.f);
+            a1.x = fmaxf(a1.x, 0.f); a1.y = fmaxf(a1.y, 0.f); a1.z = fmaxf(a1.z, 0.f); a1.w = fmaxf(a1.w, 0.f);
+            *reinterpret_cast<f32x4 *>(op + b * bstr) = a0;
+            *reinterpret_cast<f32x4 *>(op + b * bstr + 4) = a1;
+        }
+    }
+}
+
 // Last layer: Conv2d(64 -> 1, 1x1) (model.py:68,93).  HBM-bound: 16 lanes per pixel read 4 channels each,
 // 4-step xor-shuffle reduction inside the 16-lane group.  Output is always fp32.
 template <typename T>
@@ -853,7 +898,7 @@ hipError_t launch_conv_first(const float *x, const float *w9x64, const float *bi
     if (blocks <= 0 || blocks > 0x7fffffffL || lds > 160 * 1024) return hipErrorInvalidValue;   // W <= 4094
     if (lds > 64 * 1024) {
         const void *fn = f16 ? reinterpret_cast<const void *>(conv_first_kernel<_Float16>)
-                             : reinterpret_cast<const void *>(conv_first_kernel<float>);
+                             : reinterpret_cast<const void *>(conv_first_c8_kernel);
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
@@ -861,7 +906,7 @@ hipError_t launch_conv_first(const float *x, const float *w9x64, const float *bi
         hipLaunchKernelGGL(conv_first_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), lds, st, x, w9x64, bias,
                            static_cast<_Float16 *>(out), H, W, tpi);
     else
-        hipLaunchKernelGGL(conv_first_kernel<float>, dim3((unsigned)blocks), dim3(256), lds, st, x, w9x64, bias,
+        hipLaunchKernelGGL(conv_first_c8_kernel, dim3((unsigned)blocks), dim3(256), lds, st, x, w9x64, bias,
                            static_cast<float *>(out), H, W, tpi);
     return hipGetLastError();
 }
