@@ -56,6 +56,25 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg)
     return start + (b >> 3);
 }
 
+// GEMM column of the transposed convolution -> sub-pixel ij = 2*di + dj and output channel.
+//   fp16 (NHWC):  column = ij*Cout + co.
+//   fp32 (C8):    column = ((di*(Cout/64) + cg)*2 + dj)*64 + c64, co = 64*cg + c64: the 128 columns of a workgroup are both
+//                 dj of one di and 64 channels, so that its stores cover whole runs of output pixels (2*gx + dj) per
+//                 8-channel block.  pack_convt (adn_api.hip) and the bias vector follow the same order.
+template <typename T>
+__host__ __device__ __forceinline__ void convt_column(int col, int Cout, int &ij, int &co)
+{
+    if constexpr (sizeof(T) == 4) {
+        const int c64 = col & 63, dj = (col >> 6) & 1, g = col >> 7, ncg = Cout >> 6;
+        const int di = g / ncg, cg = g - di * ncg;
+        ij = 2 * di + dj;
+        co = 64 * cg + c64;
+    } else {
+        ij = col / Cout;
+        co = col - ij * Cout;
+    }
+}
+
 // Epilogue shared by the register-staged and the LDS-DMA kernels: folded-BN bias (+ ReLU, + 2x2 max-pool) or the
 // pixel-shuffle store of the transposed convolution.
 template <typename T, int TH, int BN, int WM, int WN, int EPI>
@@ -80,8 +99,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &p, f32x16 (&acc)[T
         for (int i = 0; i < MB; ++i) {
             const int trow0 = (wm * MB + i) * 2;
             if (EPI == CONVT2X2) {
-                // column = (di*2+dj)*Cout + co ; output pixel (2*gy+di, 2*gx+dj); bias only, no activation.
-                const int ij = col / p.Cout, co = col - ij * p.Cout;
+                // output pixel (2*gy+di, 2*gx+dj); bias only, no activation.  GEMM column -> (di, dj, co): see convt_column
+                int ij, co;
+                convt_column<T>(col, p.Cout, ij, co);
                 const int Ho = 2 * p.H, Wo = 2 * p.W;
                 T *ob = outp + (size_t)n * Ho * Wo * p.Cout + act_off<T>(p.Cout, (long)Ho * Wo, 0, co);
 #pragma unroll
@@ -351,7 +371,27 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs &p, f32x16 (
 
     // ---- phase 2: 16-byte pieces, LDS -> global ----
     T *outp = static_cast<T *>(p.out);
-    if constexpr (EPI == CONVT2X2) {
+    if constexpr (EPI == CONVT2X2 && sizeof(T) == 4) {
+        // fp32 / C8: the workgroup's 128 columns are (dj = 0, 1) x 64 channels of one di (convt_column): for each of the 8
+        // channel blocks and each tile row, the 16 input pixels x 2 dj x 8 channels are ONE 1 KB run of the output row
+        // 2*gy + di: 64 lanes x 16 bytes, lane = (gx, dj, half block).
+        static_assert(BN == 128 && NT % 64 == 0, "C8 transposed-convolution epilogue: 128 columns per workgroup");
+        const int Ho = 2 * p.H, Wo = 2 * p.W;
+        const int ncg = p.Cout >> 6, di = ct / ncg, cg = ct - di * ncg;
+        const size_t bstr = (size_t)Ho * Wo * 8;                                 // floats between channel blocks
+        float *ob = outp + (size_t)n * Ho * Wo * p.Cout + (size_t)(8 * cg) * bstr;
+        const int gxl = lane >> 2, dj = (lane >> 1) & 1, half = lane & 1;
+        const int gx = tx * TW + gxl;
+#pragma unroll
+        for (int it = 0; it < 8 * TH / (NT / 64); ++it) {
+            const int run = it * (NT / 64) + wave;                               // (channel block, tile row)
+            const int b8 = run / TH, py = run - b8 * TH;
+            const int gy = ty * TH + py;
+            const f32x4 val = *reinterpret_cast<const f32x4 *>(stage + (py * TW + gxl) * RS + dj * 64 + b8 * 8 + half * 4);
+            if (gy < p.H && gx < p.W)
+                *reinterpret_cast<f32x4 *>(ob + b8 * bstr + ((size_t)(2 * gy + di) * Wo + 2 * gx + dj) * 8 + half * 4) = val;
+        }
+    } else if constexpr (EPI == CONVT2X2) {
         // GEMM column = (di*2+dj)*Cout + co ; input pixel (gy, gx) -> output pixel (2*gy+di, 2*gx+dj)
         const int Ho = 2 * p.H, Wo = 2 * p.W;
 #pragma unroll
@@ -600,9 +640,9 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void conv_dma(const ConvArgs p)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    // fp16: LDS-staged 16-byte stores (2-byte stores per lane otherwise).  fp32 (transposed convolutions): direct 4-byte
-    // stores -- staging measured no gain there, and its 66 KB tile would cap the kernel at two workgroups per CU.
-    if constexpr (sizeof(T) == 2) {
+    // fp16: LDS-staged 16-byte stores (2-byte stores per lane otherwise).  fp32 transposed convolutions (C8 layout): staged
+    // too -- a lane's direct stores would be 4 bytes into 32-byte segments, the staged form writes 1 KB runs.
+    if constexpr (sizeof(T) == 2 || EPI == CONVT2X2) {
         static_assert((size_t)TH * TW * (BN + 16 / sizeof(T)) * sizeof(T) <= C::LDS_BYTES, "staging tile must fit the two images");
         conv_epilogue_staged<T, TH, BN, WM, WN, EPI>(p, acc, bias_r, smem, tid, lane, wave, ct, n, ty, tx);
     } else {
