@@ -477,9 +477,7 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
         // instead).  Not when block outputs are exported (the up4 tap IS that tensor).
         // fp16 path: a workgroup of conv_dma holds all 64 channels, the dot is finished in its epilogue (writes y).
         const bool fuse_f16 = l == 0 && f16 && !taps && b.nct == 1;
-        // (where the F(4x4,3x3) kernel applies it takes this layer unfused: faster than the fused F(2x2,3x3) form)
-        fused_out = l == 0 && h->use_wino && !taps && b.nct == 2 &&
-                    !(b.wpk4 && adn::wino4_applicable(adn::CONV3X3_RELU, b, h->force_wino4));
+        fused_out = l == 0 && h->use_wino && !taps && b.nct == 2;
         if (fused_out) {
             b.dotw = h->dev + h->out_w;
             b.dot_out = static_cast<float *>(Y);

@@ -336,6 +336,48 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const float *xr = smem + ((tb * 2 + (jh ^ 1)) * 16 * 64 + lane) * 4;  // the partner's block: its sum for OUR cout block
     const int Hp = p.H >> 1, Wp = p.W >> 1;
     const int col = ct * 32 + 16 * jh + ti;
+    if constexpr (EPI == CONV3X3_RELU_DOT) {
+        // Fused last layer (model.py:91,93): out[px] += sum over this workgroup's 32 couts of w1x1[c] * ReLU(conv[c][px] + bias[c]);
+        // the 64-channel tensor is never written.  Each lane forms w * value for its cout and its 64 pixels, the 16 couts of
+        // a wave and the two waves of a tile block meet in LDS ([wave][pixel][16 + pad]) and one thread per pixel adds the 32
+        // terms in a fixed order: deterministic, no atomics.  launch_dot_finish adds the planes of the cout tiles + bias.
+        const float wdot = p.dotw[col];
+        float yf[4][4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            partial(acc[0], r, yf[r]);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const f32x4 o = *reinterpret_cast<const f32x4 *>(xr + (r * 4 + a) * 256);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) yf[r][a][b] = wdot * fmaxf(yf[r][a][b] + o[b] + bias_r, 0.f);
+            }
+        }
+        __syncthreads();                                // every wave has read its partner's exchange block
+        constexpr int DSTR = 256 * 17 + 32;             // floats per wave: [pixel][17] + 8 floats of skew per tile row
+        float *dw = smem + wave * DSTR + q * 8 + ti;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) dw[((4 * q + a) * 16 + 4 * r + b) * 17] = yf[r][a][b];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int P = k * NT + tid;                 // pixel of the 32x32 tile: block P >> 8, row (P >> 4) & 15, column P & 15
+            const int blk = P >> 8, px = P & 255;
+            const float *s0 = smem + (blk * 2) * DSTR + px * 17 + (px >> 6) * 8;
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sum += s0[i];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sum += s0[DSTR + i];
+            const int gy = ty * REG + 16 * (blk >> 1) + (px >> 4), gx = tx * REG + 16 * (blk & 1) + (px & 15);
+            if (gy < p.H && gx < p.W) p.dot_out[(((size_t)ct * p.N + n) * p.H + gy) * p.W + gx] = sum;
+        }
+        return;
+    }
     float *ob = static_cast<float *>(p.out) + (size_t)n * p.H * p.W * p.Cout + act_off<float>(p.Cout, (long)p.H * p.W, 0, col);
     float *pb = (EPI == CONV3X3_RELU_POOL)
                     ? static_cast<float *>(p.pool) + (size_t)n * Hp * Wp * p.Cout + act_off<float>(p.Cout, (long)Hp * Wp, 0, col)
@@ -376,7 +418,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // force: every plain / pooled layer whatever its size (ADN_WINO_TILE=4; parity tests of the tile-edge handling).
 bool wino4_applicable(ConvKind kind, const ConvArgs &a, bool force)
 {
-    if (kind != CONV3X3_RELU && kind != CONV3X3_RELU_POOL) return false;
+    if (kind != CONV3X3_RELU && kind != CONV3X3_RELU_POOL && kind != CONV3X3_RELU_DOT) return false;
+    if (kind == CONV3X3_RELU_DOT && (!a.dotw || !a.dot_out)) return false;
     if (a.firstw || a.ksplit > 1 || (a.Cout & 31) || a.nchunk < 1) return false;
     const long th = (a.H + REG - 1) / REG, tw = (a.W + REG - 1) / REG;
     return force || th * tw * REG * REG * 3 <= (long)a.H * a.W * 4;
@@ -406,8 +449,11 @@ hipError_t launch_wino4_conv(ConvKind kind, const ConvArgs &a, hipStream_t st)
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_conv_f32<CONV3X3_RELU>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_conv_f32<CONV3X3_RELU_DOT>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         if (e1 != hipSuccess) return e1;
         if (e2 != hipSuccess) return e2;
+        if (e3 != hipSuccess) return e3;
         attr_mask.fetch_or(bit, std::memory_order_release);
     }
 #ifdef ADN_EXPERIMENTS
@@ -426,7 +472,10 @@ hipError_t launch_wino4_conv(ConvKind kind, const ConvArgs &a, hipStream_t st)
         return hipLaunchKernel(f, dim3((unsigned)nwg), dim3(NT), args, LDS_BYTES, st);
     }
 #endif
-    if (kind == CONV3X3_RELU_POOL)
+    static_assert(8 * (256 * 17 + 32) * sizeof(float) <= LDS_BYTES, "staging of the fused 1x1 epilogue must fit the images");
+    if (kind == CONV3X3_RELU_DOT)
+        hipLaunchKernelGGL(wino4_conv_f32<CONV3X3_RELU_DOT>, dim3((unsigned)nwg), dim3(NT), LDS_BYTES, st, a2);
+    else if (kind == CONV3X3_RELU_POOL)
         hipLaunchKernelGGL(wino4_conv_f32<CONV3X3_RELU_POOL>, dim3((unsigned)nwg), dim3(NT), LDS_BYTES, st, a2);
     else
         hipLaunchKernelGGL(wino4_conv_f32<CONV3X3_RELU>, dim3((unsigned)nwg), dim3(NT), LDS_BYTES, st, a2);

@@ -16,14 +16,29 @@ def _ceil_to(v: int, m: int) -> int:
     return (v + m - 1) // m * m
 
 
-def executed_mfma_flops(launch: dict, algo: str) -> float:
+def winograd_tile(launch: dict, mode: str = "auto") -> int:
+    """Which Winograd form libadn's fp32 path runs a 3x3 launch with (mirrors ``wino4_applicable`` in
+    csrc/wino4_kernels.hip): 4 = F(4x4,3x3) on 32x32-pixel workgroup tiles where they cover the layer with at most a
+    quarter of the tiled area outside the image, else 2 = F(2x2,3x3) on 16x16-pixel tiles.  ``mode``: the handle's
+    ADN_WINO_TILE setting ("auto", "2" or "4")."""
+    if launch["kind"] != "conv3x3" or mode == "2":
+        return 2
+    if mode == "4":
+        return 4
+    h, w = launch["h"], launch["w"]
+    return 4 if _ceil_to(h, 32) * _ceil_to(w, 32) * 3 <= h * w * 4 else 2
+
+
+def executed_mfma_flops(launch: dict, algo: str, wino_mode: str = "auto") -> float:
     """Matrix-core FLOPs one launch EXECUTES per sample, padded tiles counted (what `roofline.frac` is made of).
 
-    ``algo``: "winograd" (wino_conv_dma_f32: 16x16-pixel tiles, F(2x2,3x3) = 16 multiply-adds per 2x2 output tile and
-    (cin, cout) pair instead of 36, i.e. 8 FLOP per padded output pixel and channel pair), "direct" (conv_mfma<float>:
-    TH x 16 tiles with TH = 16 for the 64-channel layers and 8 otherwise) or "direct_f16" (conv_dma<_Float16>: 32 x 16
-    tiles for every layer).  Transposed convolutions run conv_dma<T, 8, 128, ...>: K = Cin, 4*Cout GEMM columns, 8 x 16
-    tiles of input pixels.  The first (Cin = 1) and last (1x1, Cout = 1) layers do not use the matrix cores: 0."""
+    ``algo``: "winograd" (fp32 default: wino4_conv_f32 = F(4x4,3x3), 36 multiply-adds per 4x4 output tile and (cin, cout)
+    pair = 4.5 FLOP per padded output pixel on 32x32 tiles, where ``winograd_tile`` says so; wino_conv_dma_f32 =
+    F(2x2,3x3), 16 multiply-adds per 2x2 tile = 8 FLOP per padded pixel on 16x16 tiles, elsewhere), "direct"
+    (conv_mfma<float>: TH x 16 tiles with TH = 16 for the 64-channel layers and 8 otherwise, 18 FLOP per pixel) or
+    "direct_f16" (conv_dma<_Float16>: 32 x 16 tiles for every layer).  Transposed convolutions run
+    conv_dma<T, 8, 128, ...>: K = Cin, 4*Cout GEMM columns, 8 x 16 tiles of input pixels.  The first (Cin = 1) and
+    last (1x1, Cout = 1) layers do not use the matrix cores: 0."""
     kind = launch["kind"]
     if kind in ("first", "out"):
         return 0.0
@@ -31,6 +46,8 @@ def executed_mfma_flops(launch: dict, algo: str) -> float:
     if kind == "convt":
         return 2.0 * cin * 4 * cout * _ceil_to(h, 8) * _ceil_to(w, 16)
     if algo == "winograd":
+        if winograd_tile(launch, wino_mode) == 4:
+            return 4.5 * cin * cout * _ceil_to(h, 32) * _ceil_to(w, 32)
         return 8.0 * cin * cout * _ceil_to(h, 16) * _ceil_to(w, 16)
     th = 32 if algo == "direct_f16" else (16 if cout == 64 else 8)
     return 18.0 * cin * cout * _ceil_to(h, th) * _ceil_to(w, 16)

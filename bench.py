@@ -11,14 +11,16 @@ the per-clip values (4 floats per clip).  Clips shard over ranks, weights are re
 collective; weak scaling: the batch per GPU is fixed.  Rank 0 prints ONE JSON line; `value` = all ranks' frames /
 max-over-ranks time between barrier + synchronize pairs.
 
-roofline (dominant kernel = the 17 3x3 convolutions, 95 % of the FLOPs; wino_conv_dma_f32, Winograd F(2x2,3x3) on the
-exact-fp32 matrix cores; ADN_CONV_ALGO=direct selects the direct implicit-GEMM kernel conv_mfma<float>):
+roofline (dominant kernel = wino4_conv_f32, Winograd F(4x4,3x3) on the exact-fp32 matrix cores: 15 of the 17 3x3
+convolutions at 513x256, 85 % of the forward's time; the 32x16 bottleneck stays on wino_conv_dma_f32, F(2x2,3x3), and is
+summarised under `other_3x3_kernel`; ADN_WINO_TILE=2 pins F(2x2,3x3) everywhere, ADN_CONV_ALGO=direct selects the direct
+implicit-GEMM kernel conv_mfma<float>):
   every launch of the timed steps is bracketed with hipEvents on the launch stream inside libadn
   (adn_unet_set_timing).  `achieved` = matrix-core FLOPs the kernel EXECUTES per launch (padded tiles counted;
-  Winograd needs 16 multiply-adds per 2x2 output tile and channel pair, audiodenoiser_amd/roofline.py) / average
+  F(4x4,3x3) needs 36 multiply-adds per 4x4 output tile and channel pair, audiodenoiser_amd/roofline.py) / average
   launch duration; `peak` = 157.3 TFLOP/s dense fp32 MFMA (MI355X_MICROARCH.md); `frac` = achieved / peak <= 1.
-  The ALGORITHMIC (direct-convolution) rate of the same launches is under `algorithmic`; it may
-  exceed the direct-convolution roof because Winograd executes 1/2.25 of those FLOPs.
+  The ALGORITHMIC (direct-convolution) rate of the same launches is under `algorithmic`; it
+  exceeds the direct-convolution roof because F(4x4,3x3) executes a quarter of those FLOPs.
   `traffic` = HBM bytes per launch from two separate rocprofv3 --pmc passes (2 x FETCH_SIZE + WRITE_SIZE, gfx950
   correction), read from profiles/pmc_traffic.json ONLY if that file was produced from this very build of libadn.so
   (source digest recorded in it); null otherwise.
@@ -149,38 +151,58 @@ def launch_timings(net, steps):
     return ms.mean(axis=0)
 
 
-def conv_roofline(ms_mean, b, algo, peak, kernel_name, traffic_key):
-    """MFMA roofline of the 17 3x3 launches from their event-timed durations (see the module docstring)."""
-    from audiodenoiser_amd.roofline import executed_mfma_flops, unet_launches
+def conv_roofline(ms_mean, b, algo, peak, kernel_name, traffic_key, wino_mode="auto"):
+    """MFMA roofline of the dominant 3x3 kernel from the event-timed durations of its launches (module docstring).
+
+    fp32 Winograd path: the dominant kernel is wino4_conv_f32 (F(4x4,3x3)); the 3x3 launches that stay on
+    wino_conv_dma_f32 (F(2x2,3x3): the 32x16 bottleneck at 513x256) are summarised under `other_3x3_kernel`."""
+    from audiodenoiser_amd.roofline import executed_mfma_flops, unet_launches, winograd_tile
     launches = unet_launches(F_BINS, T_FRAMES)
-    dom = [i for i, l in enumerate(launches) if l["kind"] == "conv3x3"]
-    dom_ms = float(ms_mean[dom].sum())
-    executed = sum(executed_mfma_flops(launches[i], algo) for i in dom) * b
-    algorithmic = sum(launches[i]["flops"] for i in dom) * b
+    conv = [i for i, l in enumerate(launches) if l["kind"] == "conv3x3"]
+    dom = [i for i in conv if algo != "winograd" or winograd_tile(launches[i], wino_mode) == 4] or conv
+    rest = [i for i in conv if i not in dom]
+
+    def rates(idx):
+        ms = float(ms_mean[idx].sum())
+        executed = sum(executed_mfma_flops(launches[i], algo, wino_mode) for i in idx) * b
+        algorithmic = sum(launches[i]["flops"] for i in idx) * b
+        return ms, executed, algorithmic
+
+    dom_ms, executed, algorithmic = rates(dom)
     ach = executed / (dom_ms * 1e-3) / 1e12
     alg = algorithmic / (dom_ms * 1e-3) / 1e12
     traffic, source = tracked_traffic(traffic_key)
-    return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-            "traffic": traffic, "traffic_source": source,
-            "kernel": f"{kernel_name}, {len(dom)} launches per forward",
-            "achieved_basis": "matrix-core FLOPs executed per launch (padded tiles counted) / event-timed launch duration",
-            "executed_flops_per_launch": round(executed / len(dom), 1),
-            "avg_launch_ms": round(dom_ms / len(dom), 4),
-            "algorithmic": {"flops_per_launch": round(algorithmic / len(dom), 1), "tflops": round(alg, 2),
-                            "frac_of_direct_conv_roof": round(alg / peak, 4),
-                            "note": "direct-convolution FLOP count of SURVEY.md 8d; Winograd executes 1/2.25 of it"},
-            "algorithmic_bytes_per_launch": round(sum(launches[i]["act_bytes"] * b + launches[i]["weight_bytes"]
-                                                      for i in dom) / len(dom) * (0.5 if algo == "direct_f16" else 1.0))}
+    out = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+           "traffic": traffic, "traffic_source": source,
+           "kernel": f"{kernel_name}, {len(dom)} launches per forward",
+           "achieved_basis": "matrix-core FLOPs executed per launch (padded tiles counted) / event-timed launch duration",
+           "executed_flops_per_launch": round(executed / len(dom), 1),
+           "avg_launch_ms": round(dom_ms / len(dom), 4),
+           "algorithmic": {"flops_per_launch": round(algorithmic / len(dom), 1), "tflops": round(alg, 2),
+                           "frac_of_direct_conv_roof": round(alg / peak, 4),
+                           "note": "direct-convolution FLOP count of SURVEY.md 8d; Winograd F(4x4,3x3) executes 1/4 of "
+                                   "it, F(2x2,3x3) 1/2.25"},
+           "algorithmic_bytes_per_launch": round(sum(launches[i]["act_bytes"] * b + launches[i]["weight_bytes"]
+                                                     for i in dom) / len(dom) * (0.5 if algo == "direct_f16" else 1.0))}
+    if rest:
+        r_ms, r_exec, r_alg = rates(rest)
+        out["other_3x3_kernel"] = {
+            "kernel": "wino_conv_dma_f32 (Winograd F(2x2,3x3)): " + ", ".join(launches[i]["name"] for i in rest),
+            "launches": len(rest), "avg_launch_ms": round(r_ms / len(rest), 4),
+            "executed_mfma_tflops": round(r_exec / (r_ms * 1e-3) / 1e12, 2),
+            "frac": round(r_exec / (r_ms * 1e-3) / 1e12 / peak, 4),
+            "algorithmic_tflops": round(r_alg / (r_ms * 1e-3) / 1e12, 2)}
+    return out
 
 
-def forward_summary(ms_mean, b, algo, peak):
+def forward_summary(ms_mean, b, algo, peak, wino_mode="auto"):
     from audiodenoiser_amd.roofline import PEAK_HBM_GBS, executed_mfma_flops, unet_launches
     launches = unet_launches(F_BINS, T_FRAMES)
     half = 0.5 if algo == "direct_f16" else 1.0
     fwd_ms = float(ms_mean.sum())
     tot_flops = sum(l["flops"] for l in launches) * b
-    tot_exec = sum(executed_mfma_flops(l, algo if l["kind"] == "conv3x3" else ("direct_f16" if half < 1 else "direct"))
-                   for l in launches) * b
+    tot_exec = sum(executed_mfma_flops(l, algo if l["kind"] == "conv3x3" else ("direct_f16" if half < 1 else "direct"),
+                                       wino_mode) for l in launches) * b
     tot_bytes = (sum(l["act_bytes"] for l in launches) * b + sum(l["weight_bytes"] for l in launches)) * half
     return {"kernel_ms": round(fwd_ms, 3),
             "algorithmic_tflops": round(tot_flops / (fwd_ms * 1e-3) / 1e12, 2),
@@ -369,10 +391,13 @@ def main() -> None:
         direct = f16 or not bool(net_uses_winograd())
         algo = "direct_f16" if f16 else ("direct" if direct else "winograd")
         peak = PEAK_MFMA_F16_TFLOPS if f16 else PEAK_MFMA_F32_TFLOPS
+        wmode = wino_tile_mode()
         kname = ("conv_dma<_Float16, 32, 64, ...> (LDS-DMA staged direct implicit GEMM, fp16 MFMA)" if f16 else
                  "conv_mfma<float> (direct implicit GEMM, fp32 MFMA)" if direct else
-                 "wino_conv_dma_f32 (Winograd F(2x2,3x3), fp32 MFMA v_mfma_f32_16x16x4_f32)")
-        tkey = "conv_mfma_f16" if f16 else ("conv_mfma_f32" if direct else "wino_conv_dma_f32")
+                 "wino_conv_dma_f32 (Winograd F(2x2,3x3), fp32 MFMA v_mfma_f32_16x16x4_f32)" if wmode == "2" else
+                 "wino4_conv_f32 (Winograd F(4x4,3x3), fp32 MFMA v_mfma_f32_16x16x4_f32)")
+        tkey = ("conv_mfma_f16" if f16 else "conv_mfma_f32" if direct else
+                "wino_conv_dma_f32" if wmode == "2" else "wino4_conv_f32")
         frames = b * world * T_FRAMES * args.steps
         out = {
             "metric": "spectrogram frames/sec (forward), 513x256 fp32",
@@ -393,8 +418,8 @@ def main() -> None:
                        "batch_per_gpu": b, "global_batch": b * world, "freq_bins": F_BINS, "frames": T_FRAMES,
                        "parallelism": f"clips sharded over {world} rank(s), weights replicated",
                        "timed_region_s": round(elapsed, 3), "lib_digest": lib_digest()[:12]},
-            "roofline": conv_roofline(ms_mean, b, algo, peak, kname, tkey),
-            "forward": forward_summary(ms_mean, b, algo, peak),
+            "roofline": conv_roofline(ms_mean, b, algo, peak, kname, tkey, wmode),
+            "forward": forward_summary(ms_mean, b, algo, peak, wmode),
         }
         del allv
         if world == 1 and not args.no_extras:
@@ -409,6 +434,13 @@ def main() -> None:
     D.barrier()
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def wino_tile_mode() -> str:
+    """ADN_WINO_TILE as libadn reads it when a handle is created: "2" = F(2x2,3x3) for every 3x3 layer, "4" = F(4x4,3x3)
+    for every plain 3x3 layer, anything else = per layer by tile fit (audiodenoiser_amd.roofline.winograd_tile)."""
+    v = os.environ.get("ADN_WINO_TILE", "")
+    return v if v in ("2", "4") else "auto"
 
 
 def net_uses_winograd() -> bool:

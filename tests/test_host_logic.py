@@ -373,15 +373,26 @@ def test_roofline_accounting():
     ls = unet_launches(513, 256)
     c3 = [l for l in ls if l["kind"] == "conv3x3"]
     assert len(c3) == 17
+    from audiodenoiser_amd.roofline import winograd_tile
     for l in c3:
-        w, d = executed_mfma_flops(l, "winograd"), executed_mfma_flops(l, "direct")
-        assert w <= l["flops"] / 2.25 * 1.03 and w >= l["flops"] / 2.25          # only 513 -> 528 row padding on top
+        w2, d = executed_mfma_flops(l, "winograd", "2"), executed_mfma_flops(l, "direct")
+        assert w2 <= l["flops"] / 2.25 * 1.03 and w2 >= l["flops"] / 2.25        # only 513 -> 528 row padding on top
         assert l["flops"] <= d <= l["flops"] * 1.03
+        # F(4x4,3x3): a quarter of the direct count on 32x32-pixel tiles (513 -> 544 rows); the 32x16 bottleneck's tiles
+        # would be half empty, so it stays on F(2x2,3x3) (the rule of wino4_applicable in csrc/wino4_kernels.hip)
+        w = executed_mfma_flops(l, "winograd")
+        if l["name"].startswith("bottleneck"):
+            assert winograd_tile(l) == 2 and w == w2
+        else:
+            assert winograd_tile(l) == 4 and l["flops"] / 4 <= w <= l["flops"] / 4 * 1.07
+        assert executed_mfma_flops(l, "winograd", "4") >= l["flops"] / 4
     assert executed_mfma_flops(ls[0], "winograd") == 0.0 and executed_mfma_flops(ls[-1], "direct") == 0.0
     even = unet_launches(512, 256)
     for l in even:
         if l["kind"] == "conv3x3":
-            assert executed_mfma_flops(l, "winograd") * 2.25 == l["flops"]
+            assert executed_mfma_flops(l, "winograd", "2") * 2.25 == l["flops"]
+            if winograd_tile(l) == 4:
+                assert executed_mfma_flops(l, "winograd") * 4 == l["flops"]
         if l["kind"] == "convt":
             assert executed_mfma_flops(l, "direct") == l["flops"]
 
@@ -395,12 +406,15 @@ def test_bench_roofline_objects_from_synthetic_timings():
     spec.loader.exec_module(bench)
     from audiodenoiser_amd.roofline import PEAK_MFMA_F16_TFLOPS, PEAK_MFMA_F32_TFLOPS, unet_launches
     launches = unet_launches(513, 256)
-    ms = np.array([0.4 if l["kind"] == "first" else 0.03 if l["kind"] == "out" else 1.2 if l["kind"] == "convt"
-                   else 2.8 * l["flops"] / 9.68e9 for l in launches], dtype=np.float32)
-    r = bench.conv_roofline(ms, 64, "winograd", PEAK_MFMA_F32_TFLOPS, "wino", "wino_conv_dma_f32")
-    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and 0.5 < r["frac"] <= 1.0
+    ms = np.array([0.4 if l["kind"] == "first" else 0.45 if l["kind"] == "out" else 1.2 if l["kind"] == "convt"
+                   else 2.0 * l["flops"] / 9.68e9 for l in launches], dtype=np.float32)
+    r = bench.conv_roofline(ms, 64, "winograd", PEAK_MFMA_F32_TFLOPS, "wino4", "wino4_conv_f32")
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and 0.3 < r["frac"] <= 1.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    assert r["algorithmic"]["tflops"] > r["achieved"] * 2.2            # Winograd executes 1/2.25 of the direct count
+    assert "15 launches" in r["kernel"] and r["other_3x3_kernel"]["launches"] == 2   # the bottleneck stays on F(2x2,3x3)
+    assert r["algorithmic"]["tflops"] > r["achieved"] * 3.7            # F(4x4,3x3) executes 1/4 of the direct count
+    r2 = bench.conv_roofline(ms, 64, "winograd", PEAK_MFMA_F32_TFLOPS, "wino", "wino_conv_dma_f32", "2")
+    assert "17 launches" in r2["kernel"] and "other_3x3_kernel" not in r2 and r2["achieved"] > r["achieved"] * 1.6
     assert r["traffic"] is None or isinstance(r["traffic"], int)
     f = bench.forward_summary(ms, 64, "winograd", PEAK_MFMA_F32_TFLOPS)
     assert set(f["per_launch_ms"]) == {l["name"] for l in launches} and f["frac_mfma_peak_executed"] <= 1.0

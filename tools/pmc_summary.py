@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # kernel families bench.py asks for (key -> predicate on the short kernel name)
 FAMILIES = {
+    "wino4_conv_f32": lambda n: n.startswith("wino4_conv_f32"),
     "wino_conv_dma_f32": lambda n: n.startswith("wino_conv_dma_f32"),
     "conv_mfma_f32": lambda n: n.startswith("conv_mfma<float") and ", 9, " in n,
     "conv_mfma_f16": lambda n: n.startswith(("conv_mfma<_Float16", "conv_dma<_Float16")) and ", 9, " in n,
@@ -32,7 +33,7 @@ FAMILIES = {
     "convt_f16": lambda n: n.startswith(("conv_mfma<_Float16", "conv_dma<_Float16")) and ", 1, 4, 2" in n,
     "stft_wave_kernel": lambda n: n.startswith("stft_wave_kernel") and not n.rstrip().endswith("true>"),
     "stft_wave_kernel_fit": lambda n: n.startswith("stft_wave_kernel") and n.rstrip().endswith("true>"),
-    "conv_first_kernel": lambda n: n.startswith("conv_first_kernel<float"),
+    "conv_first_kernel": lambda n: n.startswith(("conv_first_kernel<float", "conv_first_c8_kernel")),
     "conv_out_kernel": lambda n: n.startswith("conv_out_kernel<float"),
     "conv_first_kernel_f16": lambda n: n.startswith("conv_first_kernel<_Float16"),
     "conv_out_kernel_f16": lambda n: n.startswith("conv_out_kernel<_Float16"),
