@@ -105,7 +105,8 @@ __device__ __forceinline__ void at6(float m0, float m1, float m2, float m3, floa
 
 // ABL: timing experiments (-DADN_EXPERIMENTS builds, ADN_WINO4_ABLATE): 1 no copies after the first chunk, 2 no patch
 // reads / transform, 4 no transform, 8 no barrier, 16 no B-fragment reads, 32 no U copies, 64 no halo copies, 128 every
-// copy reads the zero block; results are wrong by design.  0 in production.
+// copy reads the zero block, 256 contiguous (L1-resident) stand-in for the halo gather, 2048 no epilogue, 4096 no global
+// stores in the epilogue; results are wrong by design.  0 in production.
 template <int EPI, int ABL = 0>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino4_conv_f32(const ConvArgs p)
 {
@@ -219,7 +220,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         if (more) W4_DMA_BEGIN(c + 1);
         const float *sA = smem + (c & 1) * IMG;
         const float *sB = sA + HSLOTS * 4;
-        // one read serves both passes: .x = channel 2q (pass 0), .y = channel 2q + 1 (pass 1)
+        // one read serves both passes: .x = channel 2q (pass 0), .y = channel 2q + 1 (pass 1).  (Running the row stage of both
+        // passes as the rows land -- 36 live values instead of 60, 217 VGPRs and no spill -- measured 2.7 % slower: written this
+        // way hipcc sinks each transform operation to just in front of the MFMA group that needs it.)
         f32x2 d[6][5];
         if (!(abl & 2)) {
 #pragma unroll
@@ -297,6 +300,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #undef W4_DMA_PIECE
 #undef W4_DMA_END
 
+    if constexpr (ABL & 2048) {                         // timing experiment: no epilogue (one store keeps the accumulators alive)
+        float keep = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < 18; ++s2) keep += acc[0][s2][0] + acc[1][s2][1];
+        if (keep == 123.456f) static_cast<float *>(p.out)[tid] = keep;
+        return;
+    }
     // ---- epilogue ----
     // Y = A^T M A = sum over the transform-domain columns j of (A^T M)[.][j] * A^T[v][j]: each wave forms the sum over its
     // own three columns for both cout blocks, hands the partner's block over through LDS (the images are free: the loop
@@ -393,7 +403,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 y[a][b] = fmaxf(y[a][b] + o[b] + bias_r, 0.f);
-                if (gy + a < p.H && gx + b < p.W) ob[((size_t)(gy + a) * p.W + gx + b) * 8] = y[a][b];
+                if (gy + a < p.H && gx + b < p.W && (!(ABL & 4096) || y[a][b] == 123.456f)) ob[((size_t)(gy + a) * p.W + gx + b) * 8] = y[a][b];
             }
         }
         if (EPI == CONV3X3_RELU_POOL) {
@@ -403,7 +413,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 for (int b = 0; b < 2; ++b) {
                     const float mx = fmaxf(fmaxf(y[2 * a][2 * b], y[2 * a][2 * b + 1]), fmaxf(y[2 * a + 1][2 * b], y[2 * a + 1][2 * b + 1]));
                     const int py = (gy >> 1) + a, px = (gx >> 1) + b;
-                    if (py < Hp && px < Wp) pb[((size_t)py * Wp + px) * 8] = mx;
+                    if (py < Hp && px < Wp && (!(ABL & 4096) || mx == 123.456f)) pb[((size_t)py * Wp + px) * 8] = mx;
                 }
         }
     }
@@ -462,7 +472,7 @@ hipError_t launch_wino4_conv(ConvKind kind, const ConvArgs &a, hipStream_t st)
         switch (a2.ablate) {
 #define W4_ABL(n) case n: f = reinterpret_cast<const void *>(wino4_conv_f32<CONV3X3_RELU, n>); break;
             W4_ABL(1) W4_ABL(2) W4_ABL(4) W4_ABL(8) W4_ABL(16) W4_ABL(9) W4_ABL(18) W4_ABL(19) W4_ABL(27) W4_ABL(32) W4_ABL(64)
-            W4_ABL(128) W4_ABL(256)
+            W4_ABL(128) W4_ABL(256) W4_ABL(2048) W4_ABL(2067) W4_ABL(4096)
 #undef W4_ABL
         default: return hipErrorInvalidValue;
         }
