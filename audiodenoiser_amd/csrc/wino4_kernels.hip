@@ -107,10 +107,19 @@ __device__ __forceinline__ void at6(float m0, float m1, float m2, float m3, floa
 // reads / transform, 4 no transform, 8 no barrier, 16 no B-fragment reads, 32 no U copies, 64 no halo copies, 128 every
 // copy reads the zero block, 256 contiguous (L1-resident) stand-in for the halo gather, 2048 no epilogue, 4096 no global
 // stores in the epilogue; results are wrong by design.  0 in production.
+// lane id without the work-item-id register: values derived from threadIdx.x would otherwise have to survive the K loop
+// (in registers the loop needs, i.e. as scratch spills: measured 0.3 GB of spill traffic per full-resolution launch)
+__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
 template <int EPI, int ABL = 0>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino4_conv_f32(const ConvArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];   // the ONLY LDS object (two images)
+    // Two source forms of the same arithmetic, chosen per epilogue by measurement (hipcc's register allocation of the K loop
+    // is sensitive to what has to survive it): LEAN keeps nothing thread-id-derived alive across the loop (no scratch
+    // spills: the pooling and fused-1x1 variants run 4-6 % faster); the plain variant is faster (up to 6 %) in the other
+    // form, which spills 7 registers once per workgroup.
+    constexpr bool LEAN = EPI != CONV3X3_RELU;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -148,9 +157,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // DMA plan of the halo: slot s = r*NT + tid -> (row, pixel, channel half); offsets into the current source, -1 = zeros
     int hcur[HR];
     auto plan = [&](const ConvSrc &s) {
+        // LEAN variants: thread id rebuilt from the lane id and the plan of the second source kept inside the loop (the empty
+        // asm stops its hoisting), so that neither survives the K loop in registers
+        int t_ = LEAN ? wave * 64 + lane_id() : tid;
+        if constexpr (LEAN) asm volatile("" : "+v"(t_));
 #pragma unroll
         for (int r = 0; r < HR; ++r) {
-            const int sl = r * NT + tid;
+            const int sl = r * NT + t_;
             const int row = sl / RSL, j = sl - row * RSL;
             const int jj = j - ((row >> 2) & 3);
             const int half = jj >= HP ? 1 : 0;
@@ -189,8 +202,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         wp += USLOTS * 4;                                                                      \
     } while (0)
 
+
     // after the epilogue's exchange this wave finishes cout block jh of its tile block
-    const float bias_r = p.bias[ct * 32 + 16 * jh + ti];
+    const float bias_pre = LEAN ? 0.f : p.bias[ct * 32 + 16 * jh + ti];
 
     f32x4 acc[2][18];                                  // [cout block: 0 = the one this wave finishes (jh), 1 = the partner's][position]
 #pragma unroll
@@ -235,7 +249,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             float V[18];                                // [row i of the transform domain][own column]
             if (abl & 2) {
 #pragma unroll
-                for (int i = 0; i < 18; ++i) V[i] = bias_r + (float)i;
+                for (int i = 0; i < 18; ++i) V[i] = (float)(i + lane);
             } else if (abl & 4) {
 #pragma unroll
                 for (int i = 0; i < 18; ++i) V[i] = h ? d[i / 3][i % 3].y : d[i / 3][i % 3].x;
@@ -272,7 +286,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             f32x4 u[2];
 #define W4_LOADU(dst, g) dst = *(lds4_cv_f32x4 *)(sB + b_lane + ((g) * 2 + h) * 256)
 #define W4_LANDED(x) asm volatile("" ::"v"(x.w))
-            if (abl & 16) u[0] = u[1] = f32x4{bias_r, 1.f, 2.f, 3.f};
+            if (abl & 16) u[0] = u[1] = f32x4{(float)lane, 1.f, 2.f, 3.f};
             else W4_LOADU(u[0], 0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -311,6 +325,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // Y = A^T M A = sum over the transform-domain columns j of (A^T M)[.][j] * A^T[v][j]: each wave forms the sum over its
     // own three columns for both cout blocks, hands the partner's block over through LDS (the images are free: the loop
     // ended with a barrier) and finishes its own: lane (ti, q) = cout 16*jh + ti of the tiles (row q, columns r = 0..3).
+    const int el = LEAN ? lane_id() : lane;             // LEAN: lane-derived values are recomputed here (see lane_id)
+    const int eti = el & 15, eq = el >> 4;
+    const float bias_r = LEAN ? p.bias[ct * 32 + 16 * jh + eti] : bias_pre;
     auto partial = [&](const f32x4 *m, int r, float (&y)[4][4]) {
         float w[4][3];
 #pragma unroll
@@ -334,7 +351,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             }
         }
     };
-    float *xb = smem + ((tb * 2 + jh) * 16 * 64 + lane) * 4;           // this wave's outgoing block [16 pieces][64 lanes][4]
+    float *xb = smem + ((tb * 2 + jh) * 16 * 64 + el) * 4;           // this wave's outgoing block [16 pieces][64 lanes][4]
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         float y[4][4];
@@ -343,9 +360,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         for (int a = 0; a < 4; ++a) *reinterpret_cast<f32x4 *>(xb + (r * 4 + a) * 256) = f32x4{y[a][0], y[a][1], y[a][2], y[a][3]};
     }
     __syncthreads();
-    const float *xr = smem + ((tb * 2 + (jh ^ 1)) * 16 * 64 + lane) * 4;  // the partner's block: its sum for OUR cout block
+    const float *xr = smem + ((tb * 2 + (jh ^ 1)) * 16 * 64 + el) * 4;  // the partner's block: its sum for OUR cout block
     const int Hp = p.H >> 1, Wp = p.W >> 1;
-    const int col = ct * 32 + 16 * jh + ti;
+    const int col = ct * 32 + 16 * jh + eti;
     if constexpr (EPI == CONV3X3_RELU_DOT) {
         // Fused last layer (model.py:91,93): out[px] += sum over this workgroup's 32 couts of w1x1[c] * ReLU(conv[c][px] + bias[c]);
         // the 64-channel tensor is never written.  Each lane forms w * value for its cout and its 64 pixels, the 16 couts of
@@ -365,17 +382,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
         __syncthreads();                                // every wave has read its partner's exchange block
         constexpr int DSTR = 256 * 17 + 32;             // floats per wave: [pixel][17] + 8 floats of skew per tile row
-        float *dw = smem + wave * DSTR + q * 8 + ti;
+        float *dw = smem + wave * DSTR + eq * 8 + eti;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) dw[((4 * q + a) * 16 + 4 * r + b) * 17] = yf[r][a][b];
+                for (int b = 0; b < 4; ++b) dw[((4 * eq + a) * 16 + 4 * r + b) * 17] = yf[r][a][b];
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const int P = k * NT + tid;                 // pixel of the 32x32 tile: block P >> 8, row (P >> 4) & 15, column P & 15
+            const int P = k * NT + wave * 64 + el;      // pixel of the 32x32 tile: block P >> 8, row (P >> 4) & 15, column P & 15
             const int blk = P >> 8, px = P & 255;
             const float *s0 = smem + (blk * 2) * DSTR + px * 17 + (px >> 6) * 8;
             float sum = 0.f;
@@ -396,7 +413,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     for (int r = 0; r < 4; ++r) {
         float y[4][4];
         partial(acc[0], r, y);
-        const int gy = ty * REG + 16 * by + 4 * q, gx = tx * REG + 16 * bx + 4 * r;
+        const int gy = ty * REG + 16 * by + 4 * eq, gx = tx * REG + 16 * bx + 4 * r;
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             const f32x4 o = *reinterpret_cast<const f32x4 *>(xr + (r * 4 + a) * 256);
