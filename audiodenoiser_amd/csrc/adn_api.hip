@@ -312,6 +312,7 @@ adn::ConvArgs conv_args(const adn_unet *h, const Conv3x3Layer &L, adn::ConvKind 
     a.tilesX = (W + 15) / 16;
     a.nct = L.Cout / g.BN;
     a.ablate = 0;
+    a.pair = 0;
     a.zeros = h->dev + h->zeros_off;
     a.dbg = nullptr;
     a.ksplit = 1;
@@ -453,6 +454,7 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
         t.tilesX = (uw + 15) / 16;
         t.nct = 4 * co / g.BN;
         t.ablate = 0;
+        t.pair = 0;
         t.zeros = h->dev + h->zeros_off;
         t.dbg = nullptr;
         t.ksplit = 1;

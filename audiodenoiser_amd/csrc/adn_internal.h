@@ -42,6 +42,7 @@ struct ConvArgs {
     int N, H, W;           // tile domain: output H,W for 3x3; INPUT h,w for the transposed convolution
     int Cout;              // output channels of the layer (GEMM columns = Cout, or 4*Cout for convT)
     int tilesY, tilesX, nct;
+    int pair;              // wino4_conv_f32 only: 1 = a workgroup tile holds two clips side by side (images <= 16 px wide)
     int ablate;            // timing experiments only (ADN_WINO_ABLATE); 0 in production
     const float *zeros;    // >= 16 bytes of zeros in device memory (source of padding lanes of the LDS-DMA copy)
     void *dbg;             // diagnostic stamp buffer (ADN_WINO_STAMP); nullptr in production

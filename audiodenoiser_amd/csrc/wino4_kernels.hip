@@ -39,13 +39,19 @@ namespace {
 constexpr int KC = 8;                        // input channels per chunk
 constexpr int NT = 512;                      // threads per workgroup
 constexpr int REG = 32;                      // output pixels per workgroup edge
-constexpr int HP = REG + 2;                  // halo edge
-// LDS image (x2).  Halo: row r holds [skew(r) pad slots][34 slots: channels 0-3 of the row's pixels][34 slots: channels
-// 4-7] in RSL = 72 sixteen-byte slots, skew(r) = (r >> 2) & 3.  A patch read (ds_read_b64, served in 32-lane groups over
-// 64 banks) touches one slot per tile: the 4 tile columns are 4 slots apart, the 4 tile rows are 4*72 slots apart = 0
-// mod 16, and the skew moves them to 4 consecutive slots -> 16 different slots mod 16, conflict-free.
-constexpr int RSL = 72;
-constexpr int HR = 5;                        // DMA rounds (512 slots each) covering the 34*72 = 2448 halo slots
+constexpr int HP = REG + 2;                  // halo edge (rows; columns in the ordinary mode)
+constexpr int HPX = HP + 2;                  // pixel columns of a halo row in LDS: pair mode has two more (below)
+// LDS image (x2).  Halo: row r holds [36 slots: channels 0-3 of the row's pixels][36 slots: channels 4-7] = RSL = 72
+// sixteen-byte slots and starts at slot 72 r + (r >> 2): one pad slot in front of every fourth row.  A patch read
+// (ds_read_b64, served in 32-lane groups over 64 banks) touches one slot per tile: the 4 tile columns are 4 slots apart,
+// the 4 tile rows are 4*72 slots apart = 0 mod 16, and the pad slots move them to 4 consecutive slots -> 16 different slots
+// mod 16, conflict-free.
+// Pair mode (ConvArgs::pair, images at most 16 pixels wide -- the 32x16 bottleneck of a 513x256 input): the workgroup's
+// 32x32 tile holds the same 32 rows of TWO neighbouring clips side by side.  Halo columns 0-17 are clip A's columns
+// -1..16, columns 18-35 clip B's (both with their own zero padding), so the tile blocks of column 1 start at halo column
+// 18 instead of 16 and store to clip n + 1.
+constexpr int RSL = 2 * HPX;
+constexpr int HR = 5;                        // DMA rounds (512 slots each) covering the 34*72 + 8 = 2456 halo slots
 constexpr int HSLOTS = HR * NT;
 constexpr int USLOTS = 36 * KC * 32 / 4;     // 2304 slots: U slab, see pack_wino4_3x3 (adn_api.hip)
 constexpr int UR = (USLOTS + NT - 1) / NT;   // 5 rounds, the last one half full (waves 0-3)
@@ -141,11 +147,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int sg = lid / SUP, wl = lid - sg * SUP;
     const int ct = (sg % ncg) * gc + wl % gc;
     int pt = (sg / ncg) * gp + wl / gc;
-    if (pt >= p.N * p.tilesY * p.tilesX) return;          // padding of the last supertile (whole workgroup exits)
+    const int pair = p.pair;                              // 1: two clips side by side in the tile (see RSL above)
+    if (pt >= ((p.N + pair) >> pair) * p.tilesY * p.tilesX) return;   // padding of the last supertile (whole workgroup exits)
     const int tx = pt % p.tilesX;
     pt /= p.tilesX;
     const int ty = pt % p.tilesY;
-    const int n = pt / p.tilesY;
+    const int n = (pt / p.tilesY) << pair;               // (first) clip of the tile
     const int gy0 = ty * REG - 1, gx0 = tx * REG - 1;
 
     // U slab of the first chunk: needs no plan, flies under the index arithmetic below
@@ -164,13 +171,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
         for (int r = 0; r < HR; ++r) {
             const int sl = r * NT + t_;
-            const int row = sl / RSL, j = sl - row * RSL;
-            const int jj = j - ((row >> 2) & 3);
-            const int half = jj >= HP ? 1 : 0;
-            const int c = jj - half * HP;
-            const bool data = row < HP && jj >= 0 && jj < 2 * HP;
+            int row = sl / RSL;                           // row r starts at slot RSL*r + (r >> 2)
+            if (row * RSL + (row >> 2) > sl) --row;
+            const int j = sl - (row * RSL + (row >> 2));
+            const int half = j >= HPX ? 1 : 0;
+            int c = j - half * HPX;
+            const int second = (pair && c >= HPX / 2) ? 1 : 0;    // pair mode: the right half of the row is clip n + 1
+            c -= second * (HPX / 2);
+            const bool data = row < HP && j < RSL && c < (pair ? HPX / 2 : HP) && n + second < p.N;
             const int y = gy0 + row - s.offY, x = gx0 + c - s.offX;
-            hcur[r] = (data && y >= 0 && y < s.H && x >= 0 && x < s.W) ? (y * s.W + x) * 8 + half * 4 : -1;   // C8 layout
+            hcur[r] = (data && y >= 0 && y < s.H && x >= 0 && x < s.W) ? (y * s.W + x) * 8 + half * 4 + second * s.C * s.H * s.W : -1;   // C8 layout
         }
     };
     plan(p.s0);
@@ -215,9 +225,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // patch reads: lane (ti, q) reads channels 2q, 2q+1 (one ds_read_b64) of pixel columns jh .. jh+4 of the 6 patch rows
     // of tile (ti >> 2, ti & 3)
     const int tyl = ti >> 2, txl = ti & 3;
-    const int a_base = ((16 * by + 4 * tyl) * RSL + (q >> 1) * HP + 16 * bx + 4 * txl + jh) * 4 + 2 * (q & 1);
-    const int a_lo = a_base + tyl * 4;                      // rows 0-3 of the patch: skew = tile row
-    const int a_hi = a_base + ((tyl + 1) & 3) * 4;          // rows 4-5: the next group of four halo rows
+    const int a_base = ((16 * by + 4 * tyl) * RSL + (q >> 1) * HPX + (16 + 2 * pair) * bx + 4 * txl + jh) * 4 + 2 * (q & 1);
+    const int a_lo = a_base + (4 * by + tyl) * 4;           // rows 0-3 of the patch: pad slots in front = (row >> 2)
+    const int a_hi = a_lo + 4;                              // rows 4-5: the next group of four halo rows
     const int b_lane = (jh * 9 * 2 * 64 + lane) * 4;        // U slab [jh][group of 2 positions][pass][q][cout%16][pos%2][cout block]
 
     W4_DMA_BEGIN(0);
@@ -400,27 +410,30 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             for (int i = 0; i < 16; ++i) sum += s0[i];
 #pragma unroll
             for (int i = 0; i < 16; ++i) sum += s0[DSTR + i];
-            const int gy = ty * REG + 16 * (blk >> 1) + (px >> 4), gx = tx * REG + 16 * (blk & 1) + (px & 15);
-            if (gy < p.H && gx < p.W) p.dot_out[(((size_t)ct * p.N + n) * p.H + gy) * p.W + gx] = sum;
+            const int gy = ty * REG + 16 * (blk >> 1) + (px >> 4), gx = tx * REG + (pair ? 0 : 16 * (blk & 1)) + (px & 15);
+            const int nn = n + (pair ? (blk & 1) : 0);
+            if (gy < p.H && gx < p.W && nn < p.N) p.dot_out[(((size_t)ct * p.N + nn) * p.H + gy) * p.W + gx] = sum;
         }
         return;
     }
-    float *ob = static_cast<float *>(p.out) + (size_t)n * p.H * p.W * p.Cout + act_off<float>(p.Cout, (long)p.H * p.W, 0, col);
+    const int nb = n + (pair ? bx : 0);                 // pair mode: the tile blocks of column 1 belong to the next clip
+    const bool clip_ok = nb < p.N;
+    float *ob = static_cast<float *>(p.out) + (size_t)nb * p.H * p.W * p.Cout + act_off<float>(p.Cout, (long)p.H * p.W, 0, col);
     float *pb = (EPI == CONV3X3_RELU_POOL)
-                    ? static_cast<float *>(p.pool) + (size_t)n * Hp * Wp * p.Cout + act_off<float>(p.Cout, (long)Hp * Wp, 0, col)
+                    ? static_cast<float *>(p.pool) + (size_t)nb * Hp * Wp * p.Cout + act_off<float>(p.Cout, (long)Hp * Wp, 0, col)
                     : nullptr;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         float y[4][4];
         partial(acc[0], r, y);
-        const int gy = ty * REG + 16 * by + 4 * eq, gx = tx * REG + 16 * bx + 4 * r;
+        const int gy = ty * REG + 16 * by + 4 * eq, gx = tx * REG + (pair ? 0 : 16 * bx) + 4 * r;
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             const f32x4 o = *reinterpret_cast<const f32x4 *>(xr + (r * 4 + a) * 256);
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 y[a][b] = fmaxf(y[a][b] + o[b] + bias_r, 0.f);
-                if (gy + a < p.H && gx + b < p.W && (!(ABL & 4096) || y[a][b] == 123.456f)) ob[((size_t)(gy + a) * p.W + gx + b) * 8] = y[a][b];
+                if (clip_ok && gy + a < p.H && gx + b < p.W && (!(ABL & 4096) || y[a][b] == 123.456f)) ob[((size_t)(gy + a) * p.W + gx + b) * 8] = y[a][b];
             }
         }
         if (EPI == CONV3X3_RELU_POOL) {
@@ -430,7 +443,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 for (int b = 0; b < 2; ++b) {
                     const float mx = fmaxf(fmaxf(y[2 * a][2 * b], y[2 * a][2 * b + 1]), fmaxf(y[2 * a + 1][2 * b], y[2 * a + 1][2 * b + 1]));
                     const int py = (gy >> 1) + a, px = (gx >> 1) + b;
-                    if (py < Hp && px < Wp && (!(ABL & 4096) || mx == 123.456f)) pb[((size_t)py * Wp + px) * 8] = mx;
+                    if (clip_ok && py < Hp && px < Wp && (!(ABL & 4096) || mx == 123.456f)) pb[((size_t)py * Wp + px) * 8] = mx;
                 }
         }
     }
@@ -439,7 +452,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 }  // namespace
 
 // F(4x4,3x3) serves a layer when its 32x32-pixel workgroup tiles waste little of the image: at most a quarter of the
-// tiled area outside it (the 32x16 bottleneck and small images stay on F(2x2,3x3), whose tiles are 16x16).  The choice
+// tiled area outside it (small images stay on F(2x2,3x3), whose tiles are 16x16).  The choice
 // depends on the layer's geometry only, never on the batch: a clip's result is bit-identical whatever batch it is
 // computed in.  (Serving single clips: ADN_WINO_TILE=2 keeps the finer F(2x2,3x3) grid, which fills the chip better.)
 // force: every plain / pooled layer whatever its size (ADN_WINO_TILE=4; parity tests of the tile-edge handling).
@@ -448,8 +461,10 @@ bool wino4_applicable(ConvKind kind, const ConvArgs &a, bool force)
     if (kind != CONV3X3_RELU && kind != CONV3X3_RELU_POOL && kind != CONV3X3_RELU_DOT) return false;
     if (kind == CONV3X3_RELU_DOT && (!a.dotw || !a.dot_out)) return false;
     if (a.firstw || a.ksplit > 1 || (a.Cout & 31) || a.nchunk < 1) return false;
+    // images at most 16 pixels wide run in pair mode: a tile covers 32 rows x 16 columns of each of two clips
     const long th = (a.H + REG - 1) / REG, tw = (a.W + REG - 1) / REG;
-    return force || th * tw * REG * REG * 3 <= (long)a.H * a.W * 4;
+    const long tiled = a.W <= 16 ? th * REG * 16 : th * tw * REG * REG;
+    return force || tiled * 3 <= (long)a.H * a.W * 4;
 }
 
 hipError_t launch_wino4_conv(ConvKind kind, const ConvArgs &a, hipStream_t st)
@@ -458,9 +473,10 @@ hipError_t launch_wino4_conv(ConvKind kind, const ConvArgs &a, hipStream_t st)
     ConvArgs a2 = a;
     a2.tilesY = (a.H + REG - 1) / REG;
     a2.tilesX = (a.W + REG - 1) / REG;
+    a2.pair = a.W <= 16 ? 1 : 0;
     a2.nct = a.Cout / 32;
     const long gc = a2.nct < 8 ? a2.nct : 8, gp = SUP / gc;
-    const long ptiles = (long)a2.N * a2.tilesY * a2.tilesX;
+    const long ptiles = (long)((a2.N + a2.pair) >> a2.pair) * a2.tilesY * a2.tilesX;
     const long nwg = ((ptiles + gp - 1) / gp) * gp * a2.nct;
     if (nwg <= 0 || nwg > 0x7fffffffL) return hipErrorInvalidValue;
     a2.ablate = 0;

@@ -18,15 +18,22 @@ def _ceil_to(v: int, m: int) -> int:
 
 def winograd_tile(launch: dict, mode: str = "auto") -> int:
     """Which Winograd form libadn's fp32 path runs a 3x3 launch with (mirrors ``wino4_applicable`` in
-    csrc/wino4_kernels.hip): 4 = F(4x4,3x3) on 32x32-pixel workgroup tiles where they cover the layer with at most a
-    quarter of the tiled area outside the image, else 2 = F(2x2,3x3) on 16x16-pixel tiles.  ``mode``: the handle's
+    csrc/wino4_kernels.hip): 4 = F(4x4,3x3) on 32x32-pixel workgroup tiles (two clips side by side for images at most 16
+    pixels wide) where they cover the layer with at most a quarter of the tiled area outside the image, else 2 =
+    F(2x2,3x3) on 16x16-pixel tiles.  ``mode``: the handle's
     ADN_WINO_TILE setting ("auto", "2" or "4")."""
     if launch["kind"] != "conv3x3" or mode == "2":
         return 2
     if mode == "4":
         return 4
     h, w = launch["h"], launch["w"]
-    return 4 if _ceil_to(h, 32) * _ceil_to(w, 32) * 3 <= h * w * 4 else 2
+    return 4 if _wino4_tiled_area(h, w) * 3 <= h * w * 4 else 2
+
+
+def _wino4_tiled_area(h: int, w: int) -> int:
+    """Pixels per clip the F(4x4,3x3) workgroup tiles cover: 32x32 tiles, or -- images at most 16 pixels wide, "pair mode":
+    a tile holds the same 32 rows of two clips side by side -- 32 rows x 16 columns."""
+    return _ceil_to(h, 32) * 16 if w <= 16 else _ceil_to(h, 32) * _ceil_to(w, 32)
 
 
 def executed_mfma_flops(launch: dict, algo: str, wino_mode: str = "auto") -> float:
@@ -47,7 +54,7 @@ def executed_mfma_flops(launch: dict, algo: str, wino_mode: str = "auto") -> flo
         return 2.0 * cin * 4 * cout * _ceil_to(h, 8) * _ceil_to(w, 16)
     if algo == "winograd":
         if winograd_tile(launch, wino_mode) == 4:
-            return 4.5 * cin * cout * _ceil_to(h, 32) * _ceil_to(w, 32)
+            return 4.5 * cin * cout * _wino4_tiled_area(h, w)
         return 8.0 * cin * cout * _ceil_to(h, 16) * _ceil_to(w, 16)
     th = 32 if algo == "direct_f16" else (16 if cout == 64 else 8)
     return 18.0 * cin * cout * _ceil_to(h, th) * _ceil_to(w, 16)

@@ -11,10 +11,10 @@ the per-clip values (4 floats per clip).  Clips shard over ranks, weights are re
 collective; weak scaling: the batch per GPU is fixed.  Rank 0 prints ONE JSON line; `value` = all ranks' frames /
 max-over-ranks time between barrier + synchronize pairs.
 
-roofline (dominant kernel = wino4_conv_f32, Winograd F(4x4,3x3) on the exact-fp32 matrix cores: 15 of the 17 3x3
-convolutions at 513x256, 85 % of the forward's time; the 32x16 bottleneck stays on wino_conv_dma_f32, F(2x2,3x3), and is
-summarised under `other_3x3_kernel`; ADN_WINO_TILE=2 pins F(2x2,3x3) everywhere, ADN_CONV_ALGO=direct selects the direct
-implicit-GEMM kernel conv_mfma<float>):
+roofline (dominant kernel = wino4_conv_f32, Winograd F(4x4,3x3) on the exact-fp32 matrix cores: all 17 3x3 convolutions
+at 513x256, 87 % of the forward's time; layers whose image its 32x32 tiles do not fit -- none at this size -- run
+wino_conv_dma_f32, F(2x2,3x3), and would be summarised under `other_3x3_kernel`; ADN_WINO_TILE=2 pins F(2x2,3x3)
+everywhere, ADN_CONV_ALGO=direct selects the direct implicit-GEMM kernel conv_mfma<float>):
   every launch of the timed steps is bracketed with hipEvents on the launch stream inside libadn
   (adn_unet_set_timing).  `achieved` = matrix-core FLOPs the kernel EXECUTES per launch (padded tiles counted;
   F(4x4,3x3) needs 36 multiply-adds per 4x4 output tile and channel pair, audiodenoiser_amd/roofline.py) / average
@@ -154,8 +154,8 @@ def launch_timings(net, steps):
 def conv_roofline(ms_mean, b, algo, peak, kernel_name, traffic_key, wino_mode="auto"):
     """MFMA roofline of the dominant 3x3 kernel from the event-timed durations of its launches (module docstring).
 
-    fp32 Winograd path: the dominant kernel is wino4_conv_f32 (F(4x4,3x3)); the 3x3 launches that stay on
-    wino_conv_dma_f32 (F(2x2,3x3): the 32x16 bottleneck at 513x256) are summarised under `other_3x3_kernel`."""
+    fp32 Winograd path: the dominant kernel is wino4_conv_f32 (F(4x4,3x3)); 3x3 launches that stay on wino_conv_dma_f32
+    (F(2x2,3x3): images its 32x32 tiles do not fit; none at 513x256) are summarised under `other_3x3_kernel`."""
     from audiodenoiser_amd.roofline import executed_mfma_flops, unet_launches, winograd_tile
     launches = unet_launches(F_BINS, T_FRAMES)
     conv = [i for i, l in enumerate(launches) if l["kind"] == "conv3x3"]

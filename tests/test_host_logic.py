@@ -378,13 +378,12 @@ def test_roofline_accounting():
         w2, d = executed_mfma_flops(l, "winograd", "2"), executed_mfma_flops(l, "direct")
         assert w2 <= l["flops"] / 2.25 * 1.03 and w2 >= l["flops"] / 2.25        # only 513 -> 528 row padding on top
         assert l["flops"] <= d <= l["flops"] * 1.03
-        # F(4x4,3x3): a quarter of the direct count on 32x32-pixel tiles (513 -> 544 rows); the 32x16 bottleneck's tiles
-        # would be half empty, so it stays on F(2x2,3x3) (the rule of wino4_applicable in csrc/wino4_kernels.hip)
+        # F(4x4,3x3): a quarter of the direct count on 32x32-pixel tiles (513 -> 544 rows); the 32x16 bottleneck runs in pair
+        # mode (two clips per tile), exact fit (the rule of wino4_applicable in csrc/wino4_kernels.hip)
         w = executed_mfma_flops(l, "winograd")
+        assert winograd_tile(l) == 4 and l["flops"] / 4 <= w <= l["flops"] / 4 * 1.07
         if l["name"].startswith("bottleneck"):
-            assert winograd_tile(l) == 2 and w == w2
-        else:
-            assert winograd_tile(l) == 4 and l["flops"] / 4 <= w <= l["flops"] / 4 * 1.07
+            assert w * 4 == l["flops"]
         assert executed_mfma_flops(l, "winograd", "4") >= l["flops"] / 4
     assert executed_mfma_flops(ls[0], "winograd") == 0.0 and executed_mfma_flops(ls[-1], "direct") == 0.0
     even = unet_launches(512, 256)
@@ -411,10 +410,14 @@ def test_bench_roofline_objects_from_synthetic_timings():
     r = bench.conv_roofline(ms, 64, "winograd", PEAK_MFMA_F32_TFLOPS, "wino4", "wino4_conv_f32")
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and 0.3 < r["frac"] <= 1.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    assert "15 launches" in r["kernel"] and r["other_3x3_kernel"]["launches"] == 2   # the bottleneck stays on F(2x2,3x3)
+    assert "17 launches" in r["kernel"] and "other_3x3_kernel" not in r
     assert r["algorithmic"]["tflops"] > r["achieved"] * 3.7            # F(4x4,3x3) executes 1/4 of the direct count
     r2 = bench.conv_roofline(ms, 64, "winograd", PEAK_MFMA_F32_TFLOPS, "wino", "wino_conv_dma_f32", "2")
     assert "17 launches" in r2["kernel"] and "other_3x3_kernel" not in r2 and r2["achieved"] > r["achieved"] * 1.6
+    # a small image: the 16x16 tiles of F(2x2,3x3) fit where the 32x32 tiles would overhang
+    from audiodenoiser_amd.roofline import winograd_tile
+    assert winograd_tile({"kind": "conv3x3", "h": 33, "w": 47}) == 2 and winograd_tile({"kind": "conv3x3", "h": 64, "w": 80}) == 4
+    assert winograd_tile({"kind": "conv3x3", "h": 32, "w": 16}) == 4 and winograd_tile({"kind": "conv3x3", "h": 20, "w": 9}) == 2
     assert r["traffic"] is None or isinstance(r["traffic"], int)
     f = bench.forward_summary(ms, 64, "winograd", PEAK_MFMA_F32_TFLOPS)
     assert set(f["per_launch_ms"]) == {l["name"] for l in launches} and f["frac_mfma_peak_executed"] <= 1.0
