@@ -1,3 +1,7 @@
+#!/bin/bash
+# Round-end validation on the GPU box: all -m gpu tests, smoke(), rocprof kernel stats + PMC (tools/profile_bench.sh),
+# default bench line, batch-256 line, parity report against the reference goldens.  Outputs under gpurun_out/ (r02b_*).
+#     gpurun --timeout 1200 -- 'bash tools/round_end_run.sh'
 set -e
 python -m pytest tests -x -q -m gpu > gpurun_out/r02b_pytest_gpu.log 2>&1 || { tail -20 gpurun_out/r02b_pytest_gpu.log; exit 1; }
 tail -1 gpurun_out/r02b_pytest_gpu.log
@@ -9,6 +13,6 @@ python bench.py --batch-per-gpu 256 --steps 30 --no-extras --no-cpu-baseline > g
 (python tools/report_parity.py; ADN_WINO_TILE=2 python tools/report_parity.py | sed 's/^winograd /wino F(2,3)/'; ADN_CONV_ALGO=direct python tools/report_parity.py) > gpurun_out/r02b_parity.txt 2>/dev/null
 python -c "
 import json
-d=json.load(open('gpurun_out/r02b_bench.json')); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['traffic'], d['stft']['value'] if 'stft' in d else None, d['f16']['value'] if 'f16' in d else None, d['cpu_baseline']['value'])
+d=json.load(open('gpurun_out/r02b_bench.json')); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['traffic'], d['stft']['ms_per_launch'], d['f16']['frames_per_s'], d['cpu_baseline']['value'])
 d=json.load(open('gpurun_out/r02b_bench_b256.json')); print(d['value'], d['ms_per_step'])"
 cat gpurun_out/r02b_parity.txt
