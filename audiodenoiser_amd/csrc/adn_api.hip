@@ -193,19 +193,13 @@ void pack_wino4_3x3(const float *w /*(Cout,Cin,3,3)*/, const std::vector<float> 
 }
 
 // GEMM column of the transposed convolution -> (ij = 2*di + dj, co); must match convt_column in conv_kernels.hip:
-// fp16: col = ij*Cout + co;  fp32: col = ((di*(Cout/64) + cg)*2 + dj)*64 + c64 with co = 64*cg + c64.
-template <typename T>
+// col = ((di*(Cout/64) + cg)*2 + dj)*64 + c64 with co = 64*cg + c64.
 void convt_column_host(int col, int Cout, int &ij, int &co)
 {
-    if (sizeof(T) == 4) {
-        const int c64 = col & 63, dj = (col >> 6) & 1, g = col >> 7, ncg = Cout >> 6;
-        const int di = g / ncg, cg = g - di * ncg;
-        ij = 2 * di + dj;
-        co = 64 * cg + c64;
-    } else {
-        ij = col / Cout;
-        co = col - ij * Cout;
-    }
+    const int c64 = col & 63, dj = (col >> 6) & 1, g = col >> 7, ncg = Cout >> 6;
+    const int di = g / ncg, cg = g - di * ncg;
+    ij = 2 * di + dj;
+    co = 64 * cg + c64;
 }
 
 // ConvTranspose2d(k2,s2) as a GEMM with columns (sub-pixel, output channel) in convt_column_host order, K = Cin.
@@ -224,7 +218,7 @@ void pack_convt(const float *w /*(Cin,Cout,2,2)*/, int Cin, int Cout, T *dst)
                     for (int n = 0; n < BN; ++n) {
                         const int col = ct * BN + n;
                         int ij, co;
-                        convt_column_host<T>(col, Cout, ij, co);
+                        convt_column_host(col, Cout, ij, co);
                         for (int kk = 0; kk < EPV; ++kk) {
                             const int ci = ch * KC + 2 * EPV * s + EPV * h + kk;
                             dst[o++] = (T)w[((size_t)ci * Cout + co) * 4 + ij];
@@ -640,8 +634,7 @@ int adn_unet_create_ex(adn_unet **handle, int device, const float *const *t, int
         TL.b_off = reserve((size_t)4 * co);
         for (int col = 0; col < 4 * co; ++col) {          // bias per GEMM column
             int ij, c;
-            if (h->f16) convt_column_host<_Float16>(col, co, ij, c);
-            else convt_column_host<float>(col, co, ij, c);
+            convt_column_host(col, co, ij, c);
             host[TL.b_off + col] = t[ti + 1][c];
         }
         ti += 2;

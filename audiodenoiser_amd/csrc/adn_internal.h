@@ -6,19 +6,20 @@
 
 namespace adn {
 
-// Activation layouts inside the library (never visible at the ABI: the network input and output have one channel).
-//   fp16: NHWC.
-//   fp32: channel-blocked "C8" = [N][C/8][H][W][8].  The 3x3 kernels walk K in chunks of 8 channels and copy a halo of
-//         neighbouring pixels per chunk: in C8 a halo row of one chunk is one contiguous run (34 pixels x 32 bytes), so
-//         the LDS-DMA gather fetches whole cache lines; in NHWC every 16-byte piece sat in a different 128-byte line of
-//         which a chunk used a quarter (measured on the F(4x4,3x3) kernel: the gather pattern alone cost 8 % of the
-//         batch-64 forward).  Every C is a multiple of 8 (64 ... 1024).
-// act_off: element offset of (pixel, channel) inside one image of C channels and HW pixels.
+// Activation layout inside the library (never visible at the ABI: the network input and output have one channel):
+// channel-blocked, one block = 32 bytes of channels per pixel -- [N][C/8][H][W][8] for fp32 ("C8"), [N][C/16][H][W][16]
+// for fp16 ("C16").  The 3x3 kernels walk K in chunks of one block and copy a halo of neighbouring pixels per chunk: blocked,
+// a halo row of one chunk is one contiguous run (34 pixels x 32 bytes), so the LDS-DMA gather fetches whole cache lines; in
+// NHWC every 16-byte piece sat in a different 128-byte line of which a chunk used a quarter (measured on the F(4x4,3x3)
+// kernel: the gather pattern alone cost 8 % of the batch-64 forward).  Every C is a multiple of 16 (64 ... 1024).
+// act_off: element offset of (pixel, channel) inside one image of C channels and HW pixels; ACT_BLOCK<T>: channels per block.
+template <typename T> constexpr int ACT_BLOCK = 32 / (int)sizeof(T);
 template <typename T>
 __host__ __device__ __forceinline__ long act_off(int C, long HW, long pix, int c)
 {
-    if constexpr (sizeof(T) == 4) return ((long)(c >> 3) * HW + pix) * 8 + (c & 7);
-    else return pix * C + c;
+    constexpr int B = ACT_BLOCK<T>;
+    (void)C;
+    return ((long)(c / B) * HW + pix) * B + (c % B);
 }
 
 // One activation source of a convolution (fp32 or fp16 storage, decided by the launcher).  (offY, offX) is

@@ -4,8 +4,8 @@
 // (/root/reference/code/model.py:7-50): conv3x3+BatchNorm+ReLU, MaxPool2d(2), ConvTranspose2d(2,2),
 // F.pad + torch.cat, and the first (Cin=1) and last (1x1, Cout=1) convolutions (model.py:56,68).
 //
-// Layout: activations are NHWC (fp16) or channel-blocked [N][C/8][H][W][8] (fp32; see adn_internal.h) inside the
-// library (Cin = 1 at the entry and Cout = 1 at the exit make every layout identical at the API boundary, so no
+// Layout: activations are channel-blocked inside the library, [N][C/8][H][W][8] (fp32) or [N][C/16][H][W][16] (fp16; see
+// adn_internal.h) (Cin = 1 at the entry and Cout = 1 at the exit make every layout identical at the API boundary, so no
 // transpose is ever materialised).  Every kernel is templated on the
 // storage type T: float (exact-fp32 path) or _Float16 (fp16 storage, fp16 MFMA with fp32 accumulation —
 // BASELINE configs[4]).
@@ -56,23 +56,16 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg)
     return start + (b >> 3);
 }
 
-// GEMM column of the transposed convolution -> sub-pixel ij = 2*di + dj and output channel.
-//   fp16 (NHWC):  column = ij*Cout + co.
-//   fp32 (C8):    column = ((di*(Cout/64) + cg)*2 + dj)*64 + c64, co = 64*cg + c64: the 128 columns of a workgroup are both
-//                 dj of one di and 64 channels, so that its stores cover whole runs of output pixels (2*gx + dj) per
-//                 8-channel block.  pack_convt (adn_api.hip) and the bias vector follow the same order.
-template <typename T>
+// GEMM column of the transposed convolution -> sub-pixel ij = 2*di + dj and output channel:
+//   column = ((di*(Cout/64) + cg)*2 + dj)*64 + c64, co = 64*cg + c64: the 128 columns of a workgroup are both dj of one di and
+//   64 channels, so that its stores cover whole runs of output pixels (2*gx + dj) per channel block.  pack_convt
+//   (adn_api.hip) and the bias vector follow the same order.
 __host__ __device__ __forceinline__ void convt_column(int col, int Cout, int &ij, int &co)
 {
-    if constexpr (sizeof(T) == 4) {
-        const int c64 = col & 63, dj = (col >> 6) & 1, g = col >> 7, ncg = Cout >> 6;
-        const int di = g / ncg, cg = g - di * ncg;
-        ij = 2 * di + dj;
-        co = 64 * cg + c64;
-    } else {
-        ij = col / Cout;
-        co = col - ij * Cout;
-    }
+    const int c64 = col & 63, dj = (col >> 6) & 1, g = col >> 7, ncg = Cout >> 6;
+    const int di = g / ncg, cg = g - di * ncg;
+    ij = 2 * di + dj;
+    co = 64 * cg + c64;
 }
 
 // Epilogue shared by the register-staged and the LDS-DMA kernels: folded-BN bias (+ ReLU, + 2x2 max-pool) or the
@@ -90,7 +83,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &p, f32x16 (&acc)[T
     // row m of m-block i -> tile pixel (trow, tcol) = ((wm*MB+i)*2 + (m>>4), m&15).
     T *outp = static_cast<T *>(p.out);
     T *poolp = static_cast<T *>(p.pool);
-    const int ps = sizeof(T) == 4 ? 8 : p.Cout;                 // elements between neighbouring pixels (C8 / NHWC, adn_internal.h)
+    constexpr int ps = ACT_BLOCK<T>;                            // elements between neighbouring pixels (blocked layout, adn_internal.h)
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         const int col = ct * BN + (wn * NB + j) * 32 + l31;     // GEMM column
@@ -101,7 +94,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &p, f32x16 (&acc)[T
             if (EPI == CONVT2X2) {
                 // output pixel (2*gy+di, 2*gx+dj); bias only, no activation.  GEMM column -> (di, dj, co): see convt_column
                 int ij, co;
-                convt_column<T>(col, p.Cout, ij, co);
+                convt_column(col, p.Cout, ij, co);
                 const int Ho = 2 * p.H, Wo = 2 * p.W;
                 T *ob = outp + (size_t)n * Ho * Wo * p.Cout + act_off<T>(p.Cout, (long)Ho * Wo, 0, co);
 #pragma unroll
@@ -150,7 +143,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 4) void conv_mfm
     constexpr int EPV = Elem<T>::EPV;
     constexpr int HALO = (TAPS == 9) ? 1 : 0;
     constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
-    constexpr int KC = 2 * EPV * KG;            // channels per chunk (8*KG floats or 16*KG halfs = 32*KG bytes)
+    static_assert(2 * EPV == ACT_BLOCK<T>, "one k-group = one channel block of the activation layout");   // KG blocks per chunk
     constexpr int KQ = 2 * KG;                  // 16-byte vectors per pixel per chunk
     constexpr int ASTR = 8 * KG + 4;            // LDS dwords per halo pixel (+16 B pad: conflict-free b128 reads)
     constexpr int A_DW = PH * PW * ASTR;
@@ -205,9 +198,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 4) void conv_mfm
     }
     const T *srcp = static_cast<const T *>(p.s0.ptr) + (size_t)n * p.s0.H * p.s0.W * p.s0.C;
     const T *base1 = static_cast<const T *>(p.s1.ptr) + (size_t)n * p.s1.H * p.s1.W * p.s1.C;
-    // elements from one K-chunk to the next in the current source: KC channels (NHWC) or KG 8-channel blocks (C8)
-    size_t cstr = sizeof(T) == 4 ? (size_t)KG * p.s0.H * p.s0.W * 8 : (size_t)KC;
-    const size_t cstr1 = sizeof(T) == 4 ? (size_t)KG * p.s1.H * p.s1.W * 8 : (size_t)KC;
+    // elements from one K-chunk to the next in the current source: KG channel blocks of the blocked layout
+    size_t cstr = (size_t)KG * p.s0.H * p.s0.W * ACT_BLOCK<T>;
+    const size_t cstr1 = (size_t)KG * p.s1.H * p.s1.W * ACT_BLOCK<T>;
     const float *wp = static_cast<const float *>(p.wpk) + (size_t)ct * p.nchunk * B_DW;
 
     f32x4 ra[A_ROUNDS], rb[B_ROUNDS];
@@ -371,40 +364,26 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs &p, f32x16 (
 
     // ---- phase 2: 16-byte pieces, LDS -> global ----
     T *outp = static_cast<T *>(p.out);
-    if constexpr (EPI == CONVT2X2 && sizeof(T) == 4) {
-        // fp32 / C8: the workgroup's 128 columns are (dj = 0, 1) x 64 channels of one di (convt_column): for each of the 8
-        // channel blocks and each tile row, the 16 input pixels x 2 dj x 8 channels are ONE 1 KB run of the output row
-        // 2*gy + di: 64 lanes x 16 bytes, lane = (gx, dj, half block).
-        static_assert(BN == 128 && NT % 64 == 0, "C8 transposed-convolution epilogue: 128 columns per workgroup");
+    if constexpr (EPI == CONVT2X2) {
+        // The workgroup's 128 columns are (dj = 0, 1) x 64 channels of one di (convt_column): for each channel block of those
+        // 64 channels and each tile row, the 16 input pixels x 2 dj x one block are ONE 1 KB run of the output row 2*gy + di:
+        // 64 lanes x 16 bytes, lane = (gx, dj, half block).
+        static_assert(BN == 128 && NT % 64 == 0, "transposed-convolution epilogue: 128 columns per workgroup");
+        constexpr int BE = ACT_BLOCK<T>, NBLK = 64 / BE;                         // elements per block, blocks per 64 channels
         const int Ho = 2 * p.H, Wo = 2 * p.W;
         const int ncg = p.Cout >> 6, di = ct / ncg, cg = ct - di * ncg;
-        const size_t bstr = (size_t)Ho * Wo * 8;                                 // floats between channel blocks
-        float *ob = outp + (size_t)n * Ho * Wo * p.Cout + (size_t)(8 * cg) * bstr;
+        const size_t bstr = (size_t)Ho * Wo * BE;                                // elements between channel blocks
+        T *ob = outp + (size_t)n * Ho * Wo * p.Cout + (size_t)(NBLK * cg) * bstr;
         const int gxl = lane >> 2, dj = (lane >> 1) & 1, half = lane & 1;
         const int gx = tx * TW + gxl;
 #pragma unroll
-        for (int it = 0; it < 8 * TH / (NT / 64); ++it) {
+        for (int it = 0; it < NBLK * TH / (NT / 64); ++it) {
             const int run = it * (NT / 64) + wave;                               // (channel block, tile row)
             const int b8 = run / TH, py = run - b8 * TH;
             const int gy = ty * TH + py;
-            const f32x4 val = *reinterpret_cast<const f32x4 *>(stage + (py * TW + gxl) * RS + dj * 64 + b8 * 8 + half * 4);
+            const piece_t val = *reinterpret_cast<const piece_t *>(stage + (py * TW + gxl) * RS + dj * 64 + b8 * BE + half * EPP);
             if (gy < p.H && gx < p.W)
-                *reinterpret_cast<f32x4 *>(ob + b8 * bstr + ((size_t)(2 * gy + di) * Wo + 2 * gx + dj) * 8 + half * 4) = val;
-        }
-    } else if constexpr (EPI == CONVT2X2) {
-        // GEMM column = (di*2+dj)*Cout + co ; input pixel (gy, gx) -> output pixel (2*gy+di, 2*gx+dj)
-        const int Ho = 2 * p.H, Wo = 2 * p.W;
-#pragma unroll
-        for (int it = 0; it < NPIX * PPR / NT; ++it) {
-            const int id = it * NT + tid;
-            const int pix = id / PPR, part = id - pix * PPR;
-            const int gy = ty * TH + (pix >> 4), gx = tx * TW + (pix & 15);
-            const int col0 = ct * BN + part * EPP;
-            const int ij = col0 / p.Cout, co = col0 - ij * p.Cout;
-            if (gy < p.H && gx < p.W) {
-                const piece_t val = *reinterpret_cast<const piece_t *>(stage + pix * RS + part * EPP);
-                *reinterpret_cast<piece_t *>(outp + (((size_t)n * Ho + 2 * gy + (ij >> 1)) * Wo + 2 * gx + (ij & 1)) * p.Cout + co) = val;
-            }
+                *reinterpret_cast<piece_t *>(ob + b8 * bstr + ((size_t)(2 * gy + di) * Wo + 2 * gx + dj) * BE + half * EPP) = val;
         }
     } else if constexpr (EPI == CONV3X3_RELU_DOT) {
         // Fused last layer (model.py:91,93): the workgroup holds all BN = Cout channels of its pixels, so the 1x1
@@ -435,7 +414,8 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs &p, f32x16 (
             const int gy = ty * TH + (pix >> 4), gx = tx * TW + (pix & 15);
             if (gy < p.H && gx < p.W) {
                 const piece_t val = *reinterpret_cast<const piece_t *>(stage + pix * RS + part * EPP);
-                *reinterpret_cast<piece_t *>(outp + (((size_t)n * p.H + gy) * p.W + gx) * p.Cout + ct * BN + part * EPP) = val;
+                *reinterpret_cast<piece_t *>(outp + (size_t)n * p.H * p.W * p.Cout +
+                                             act_off<T>(p.Cout, (long)p.H * p.W, (long)gy * p.W + gx, ct * BN + part * EPP)) = val;
             }
         }
         if constexpr (EPI == CONV3X3_RELU_POOL) {
@@ -461,7 +441,8 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs &p, f32x16 (
                         const T a = m[e] > m1[e] ? m[e] : m1[e], b = m2[e] > m3[e] ? m2[e] : m3[e];
                         m[e] = a > b ? a : b;
                     }
-                    *reinterpret_cast<piece_t *>(poolp + (((size_t)n * Hp + py) * Wp + px) * p.Cout + ct * BN + part * EPP) = m;
+                    *reinterpret_cast<piece_t *>(poolp + (size_t)n * Hp * Wp * p.Cout +
+                                                 act_off<T>(p.Cout, (long)Hp * Wp, (long)py * Wp + px, ct * BN + part * EPP)) = m;
                 }
             }
         }
@@ -510,7 +491,7 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void conv_dma(const ConvArgs p)
 {
     using C = DmaCfg<T, TH, BN, WM, WN, TAPS, KG>;
     constexpr int NT = C::NT, EPV = Elem<T>::EPV, HALO = C::HALO, PW = C::PW;
-    constexpr int KC = 2 * EPV * KG;
+    static_assert(2 * EPV == ACT_BLOCK<T>, "one k-group = one channel block of the activation layout");   // KG blocks per chunk
     constexpr int PSLOT = C::PSLOT, RSLOT = C::RSLOT, A_SLOTS = C::A_SLOTS, SLOTS = C::SLOTS, NPIECE = C::NPIECE;
     constexpr int A_ROUNDS = C::A_ROUNDS;
     constexpr int B_DW = C::B_SLOTS * 4;                               // floats (dwords) of one chunk's weight slab
@@ -553,9 +534,9 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void conv_dma(const ConvArgs p)
     }
     const T *srcp = static_cast<const T *>(p.s0.ptr) + (size_t)n * p.s0.H * p.s0.W * p.s0.C;   // next chunk's channels
     const T *base1 = static_cast<const T *>(p.s1.ptr) + (size_t)n * p.s1.H * p.s1.W * p.s1.C;
-    // elements from one K-chunk to the next in the current source: KC channels (NHWC) or KG 8-channel blocks (C8)
-    size_t cstr = sizeof(T) == 4 ? (size_t)KG * p.s0.H * p.s0.W * 8 : (size_t)KC;
-    const size_t cstr1 = sizeof(T) == 4 ? (size_t)KG * p.s1.H * p.s1.W * 8 : (size_t)KC;
+    // elements from one K-chunk to the next in the current source: KG channel blocks of the blocked layout
+    size_t cstr = (size_t)KG * p.s0.H * p.s0.W * ACT_BLOCK<T>;
+    const size_t cstr1 = (size_t)KG * p.s1.H * p.s1.W * ACT_BLOCK<T>;
     const float *wp = static_cast<const float *>(p.wpk) + (size_t)ct * p.nchunk * B_DW;            // next chunk's slab
     const float *zsrc = p.zeros;
 
@@ -659,70 +640,17 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void conv_dma(const ConvArgs p)
 // owns 4 output channels (16-byte store for fp32, 8-byte for fp16), reads its 3 x (FIRST_PX+2) window from LDS
 // (a path of its own) and keeps the weights in registers.  Input is always fp32.
 // ------------------------------------------------------------------------------------------------
-constexpr int FIRST_PX = 8, FIRST_ROWS = 8;
+constexpr int FIRST_ROWS = 8;
 
+// One thread = one pixel, all 64 output channels block by block (blocked layout, adn_internal.h).  The 9 weights of each
+// channel are wave-uniform (scalar loads, used as scalar operands of the FMAs), the pixel's 3x3 window is read from LDS once
+// for all blocks, and a wave's two 16-byte stores per block cover 64 neighbouring pixels x 32 bytes = 2 KB contiguous.
 template <typename T>
 __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict__ x, const float *__restrict__ w9x64,
                                                          const float *__restrict__ bias, T *__restrict__ out,
                                                          int H, int W, int tiles_per_img)
 {
-    extern __shared__ float s_win[];               // (FIRST_ROWS+2) rows x (W+2), zero halo
-    const int q = threadIdx.x & 15;               // channel group: couts 4q .. 4q+3
-    const int slot = threadIdx.x >> 4;            // 16 strips per pass
-    const int n = blockIdx.x / tiles_per_img;
-    const int y0 = (blockIdx.x - n * tiles_per_img) * FIRST_ROWS;
-    const int WP = W + 2;
-    const float *xp = x + (long)n * H * W;
-    for (int i = threadIdx.x; i < (FIRST_ROWS + 2) * WP; i += 256) {
-        const int r = i / WP, c = i - r * WP;
-        const int yy = y0 + r - 1, xx = c - 1;
-        s_win[i] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? xp[(long)yy * W + xx] : 0.f;
-    }
-    f32x4 wv[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const f32x4 *>(w9x64 + t * 64 + q * 4);
-    const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + q * 4);
-    __syncthreads();
-    const int spr = (W + FIRST_PX - 1) / FIRST_PX;              // strips per row
-    const int rows = min(FIRST_ROWS, H - y0);
-    for (int s = slot; s < rows * spr; s += 16) {
-        const int r = s / spr, x0 = (s - r * spr) * FIRST_PX;
-        float v[3][FIRST_PX + 2];
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-            for (int j = 0; j < FIRST_PX + 2; ++j) v[dy][j] = s_win[(r + dy) * WP + min(x0 + j, WP - 1)];
-        // lane q owns couts 4q .. 4q+3 of 64: NHWC (fp16) or block q/2, floats 4(q&1).. of the C8 layout (fp32)
-        T *op = out + (long)n * H * W * 64 + act_off<T>(64, (long)H * W, (long)(y0 + r) * W + x0, q * 4);
-        constexpr int ps = sizeof(T) == 4 ? 8 : 64;            // elements between neighbouring pixels
-#pragma unroll
-        for (int px = 0; px < FIRST_PX; ++px) {
-            f32x4 a = bv;
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) a += wv[dy * 3 + dx] * v[dy][px + dx];
-            a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
-            if (x0 + px < W) {
-                if constexpr (sizeof(T) == 4) {
-                    *reinterpret_cast<f32x4 *>(op + px * ps) = a;
-                } else {
-                    *reinterpret_cast<f16x4 *>(op + px * ps) =
-                        f16x4{(_Float16)a.x, (_Float16)a.y, (_Float16)a.z, (_Float16)a.w};
-                }
-            }
-        }
-    }
-}
-
-// The same layer for the channel-blocked fp32 layout (C8, adn_internal.h): one thread = one pixel, all 64 output channels
-// block by block.  The 9 x 8 weights of a block are wave-uniform (scalar loads, used as scalar operands of the FMAs), the
-// pixel's 3x3 window is read from LDS once for all blocks, and a wave's two 16-byte stores per block cover 64 neighbouring
-// pixels x 32 bytes = 2 KB contiguous.
-__global__ __launch_bounds__(256) void conv_first_c8_kernel(const float *__restrict__ x, const float *__restrict__ w9x64,
-                                                            const float *__restrict__ bias, float *__restrict__ out,
-                                                            int H, int W, int tiles_per_img)
-{
+    constexpr int BE = ACT_BLOCK<T>, NV = BE / 4;  // channels per block, float4 accumulators per block
     extern __shared__ float s_win[];               // (FIRST_ROWS+2) rows x (W+2), zero halo
     const int n = blockIdx.x / tiles_per_img;
     const int y0 = (blockIdx.x - n * tiles_per_img) * FIRST_ROWS;
@@ -735,7 +663,7 @@ __global__ __launch_bounds__(256) void conv_first_c8_kernel(const float *__restr
     }
     __syncthreads();
     const int rows = min(FIRST_ROWS, H - y0);
-    const size_t bstr = (size_t)H * W * 8;         // floats between channel blocks
+    const size_t bstr = (size_t)H * W * BE;        // elements between channel blocks
     for (int i = threadIdx.x; i < rows * W; i += 256) {
         const int r = i / W, xx = i - r * W;
         float v[9];
@@ -743,19 +671,30 @@ __global__ __launch_bounds__(256) void conv_first_c8_kernel(const float *__restr
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) v[dy * 3 + dx] = s_win[(r + dy) * WP + xx + dx];
-        float *op = out + (size_t)n * H * W * 64 + ((size_t)(y0 + r) * W + xx) * 8;
+        T *op = out + (size_t)n * H * W * 64 + ((size_t)(y0 + r) * W + xx) * BE;
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            f32x4 a0 = *reinterpret_cast<const f32x4 *>(bias + b * 8), a1 = *reinterpret_cast<const f32x4 *>(bias + b * 8 + 4);
+        for (int b = 0; b < 64 / BE; ++b) {
+            f32x4 a[NV];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                a0 += *reinterpret_cast<const f32x4 *>(w9x64 + t * 64 + b * 8) * v[t];
-                a1 += *reinterpret_cast<const f32x4 *>(w9x64 + t * 64 + b * 8 + 4) * v[t];
+            for (int k = 0; k < NV; ++k) a[k] = *reinterpret_cast<const f32x4 *>(bias + b * BE + 4 * k);
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int k = 0; k < NV; ++k) a[k] += *reinterpret_cast<const f32x4 *>(w9x64 + t * 64 + b * BE + 4 * k) * v[t];
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                a[k].x = fmaxf(a[k].x, 0.f); a[k].y = fmaxf(a[k].y, 0.f); a[k].z = fmaxf(a[k].z, 0.f); a[k].w = fmaxf(a[k].w, 0.f);
             }
-            a0.x = fmaxf(a0.x, 0.f); a0.y = fmaxf(a0.y, 0.f); a0.z = fmaxf(a0.z, 0.f); a0.w = fmaxf(a0.w, 0.f);
-            a1.x = fmaxf(a1.x, 0.f); a1.y = fmaxf(a1.y, 0.f); a1.z = fmaxf(a1.z, 0.f); a1.w = fmaxf(a1.w, 0.f);
-            *reinterpret_cast<f32x4 *>(op + b * bstr) = a0;
-            *reinterpret_cast<f32x4 *>(op + b * bstr + 4) = a1;
+            if constexpr (sizeof(T) == 4) {
+#pragma unroll
+                for (int k = 0; k < NV; ++k) *reinterpret_cast<f32x4 *>(op + b * bstr + 4 * k) = a[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < NV; k += 2)
+                    *reinterpret_cast<f16x8 *>(op + b * bstr + 4 * k) =
+                        f16x8{(_Float16)a[k].x, (_Float16)a[k].y, (_Float16)a[k].z, (_Float16)a[k].w,
+                              (_Float16)a[k + 1].x, (_Float16)a[k + 1].y, (_Float16)a[k + 1].z, (_Float16)a[k + 1].w};
+            }
         }
     }
 }
@@ -775,11 +714,12 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const T *__restrict__ in,
         const long pix = base + slot;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (pix < npix) {
+            const long img = pix / HW;                                 // blocked layout: per image, blocks of HW pixels
+            const T *src = in + img * HW * 64 + act_off<T>(64, HW, pix - img * HW, q * 4);
             if constexpr (sizeof(T) == 4) {
-                const long img = pix / HW;                             // C8: 8 blocks of HW pixels x 8 channels per image
-                v = *reinterpret_cast<const f32x4 *>(in + img * HW * 64 + act_off<float>(64, HW, pix - img * HW, q * 4));
+                v = *reinterpret_cast<const f32x4 *>(src);
             } else {
-                const f16x4 hv = *reinterpret_cast<const f16x4 *>(in + pix * 64 + q * 4);
+                const f16x4 hv = *reinterpret_cast<const f16x4 *>(src);
                 v = f32x4{(float)hv.x, (float)hv.y, (float)hv.z, (float)hv.w};
             }
         }
@@ -938,7 +878,7 @@ hipError_t launch_conv_first(const float *x, const float *w9x64, const float *bi
     if (blocks <= 0 || blocks > 0x7fffffffL || lds > 160 * 1024) return hipErrorInvalidValue;   // W <= 4094
     if (lds > 64 * 1024) {
         const void *fn = f16 ? reinterpret_cast<const void *>(conv_first_kernel<_Float16>)
-                             : reinterpret_cast<const void *>(conv_first_c8_kernel);
+                             : reinterpret_cast<const void *>(conv_first_kernel<float>);
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
@@ -946,7 +886,7 @@ hipError_t launch_conv_first(const float *x, const float *w9x64, const float *bi
         hipLaunchKernelGGL(conv_first_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), lds, st, x, w9x64, bias,
                            static_cast<_Float16 *>(out), H, W, tpi);
     else
-        hipLaunchKernelGGL(conv_first_c8_kernel, dim3((unsigned)blocks), dim3(256), lds, st, x, w9x64, bias,
+        hipLaunchKernelGGL(conv_first_kernel<float>, dim3((unsigned)blocks), dim3(256), lds, st, x, w9x64, bias,
                            static_cast<float *>(out), H, W, tpi);
     return hipGetLastError();
 }
