@@ -38,8 +38,8 @@ struct ConvArgs {
     const void *wpk;       // packed weights, see pack_* in adn_api.hip
     const void *wpk4;      // fp32 3x3 layers: the same weights packed for the F(4x4,3x3) kernel (pack_wino4_3x3), or nullptr
     const float *bias;     // per GEMM column (BatchNorm folded), always fp32
-    void *out;             // NHWC output
-    void *pool;            // optional 2x2 max-pooled NHWC output (CONV3X3_RELU_POOL)
+    void *out;             // output in the blocked layout (above)
+    void *pool;            // optional 2x2 max-pooled output, same layout (CONV3X3_RELU_POOL)
     int N, H, W;           // tile domain: output H,W for 3x3; INPUT h,w for the transposed convolution
     int Cout;              // output channels of the layer (GEMM columns = Cout, or 4*Cout for convT)
     int tilesY, tilesX, nct;
@@ -59,7 +59,7 @@ struct ConvArgs {
     float dot_bias;        // fp16 kernel only (one workgroup holds all 64 channels: dot_out IS the network output)
     // Fused first layer (Winograd kernel, down1's second conv): s0.ptr is the network INPUT (N,1,H,W) and the halo of the
     // 64-channel tensor Conv2d(1->64)+BN+ReLU (model.py:11-13 via :56) is computed on the fly from firstw [9 taps][64] and
-    // firstb [64] (BatchNorm folded) instead of being copied; nullptr = ordinary NHWC source
+    // firstb [64] (BatchNorm folded) instead of being copied; nullptr = ordinary activation source
     const float *firstw, *firstb;
 };
 
@@ -99,7 +99,7 @@ long wino_workgroups(const ConvArgs &a);
 bool wino4_applicable(ConvKind kind, const ConvArgs &a, bool force);
 hipError_t launch_wino4_conv(ConvKind kind, const ConvArgs &a, hipStream_t st);
 
-// First layer: Conv2d(1 -> 64, 3x3, pad 1) + folded BN + ReLU, fp32 input, NHWC output.  w9x64: [tap][cout].
+// First layer: Conv2d(1 -> 64, 3x3, pad 1) + folded BN + ReLU, fp32 input, blocked-layout output.  w9x64: [tap][cout].
 hipError_t launch_conv_first(const float *x, const float *w9x64, const float *bias, void *out, bool f16,
                              int N, int H, int W, hipStream_t st);
 // y[i] = bias + sum over `planes` partial planes of CONV3X3_RELU_DOT (fixed order): the tail of the fused last layer.
@@ -107,7 +107,7 @@ hipError_t launch_dot_finish(const float *planes, int nplanes, float bias, float
 // Last layer: Conv2d(64 -> 1, 1x1), fp32 output.
 hipError_t launch_conv_out(const void *in, bool f16, const float *w64, float bias, float *out, long npix, long HW,
                            hipStream_t st);
-// NHWC -> NCHW fp32 (parity-test export only).
+// internal blocked layout -> NCHW fp32 (parity-test export only).
 hipError_t launch_nhwc_to_nchw(const void *in, bool f16, float *out, int N, int H, int W, int C, hipStream_t st);
 
 hipError_t launch_stft_mag(const float *audio, int n_clips, long L, int n_fft, int hop, int center, long n_frames,

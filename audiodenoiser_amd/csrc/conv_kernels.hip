@@ -25,7 +25,7 @@
 //   host-side weight packing ([tap][kgroup][half][column][16 bytes]) are therefore identical for both types.
 //   Concat + pad of the up path is virtual: a chunk is fetched from the skip tensor or from the upsampled
 //   tensor (with its pad offset) — torch.cat / F.pad never touch memory.
-//   Epilogue: folded-BN bias + ReLU, NHWC store, and (down path) the 2x2 max-pool computed in-lane from
+//   Epilogue: folded-BN bias + ReLU, store in the blocked layout, and (down path) the 2x2 max-pool computed in-lane from
 //   the accumulator registers (the four pixels of a pool window live in one lane by construction).
 #include "adn_internal.h"
 
@@ -745,7 +745,7 @@ __global__ __launch_bounds__(256) void dot_finish_kernel(const float *__restrict
     }
 }
 
-// internal layout (NHWC fp16 / C8 fp32, adn_internal.h) -> NCHW fp32 through a 32x33 LDS tile (parity-test export only).
+// internal blocked layout (adn_internal.h) -> NCHW fp32 through a 32x33 LDS tile (parity-test export only).
 template <typename T>
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T *__restrict__ in, float *__restrict__ out,
                                                            long HW, int C)

@@ -41,7 +41,8 @@ extern "C" {
 #define ADN_N_WEIGHT_TENSORS 118   /* state_dict float tensors (136 entries minus 18 num_batches_tracked) */
 #define ADN_N_TAPS 10              /* down1..down4, bottleneck, up1..up4, out */
 #define ADN_N_LAUNCHES 23          /* timing slots per forward: first conv, 17 MFMA 3x3 convs, 4 convT, 1x1 out; a slot
-                                      whose layer runs fused into its neighbour (first conv, 1x1 out) stays ~0 */
+                                      whose layer runs fused into its neighbour (1x1 out: only the tail that adds the
+                                      partial planes remains; first conv on the F(2x2,3x3) path) stays ~0 */
 
 typedef struct adn_unet adn_unet;
 
