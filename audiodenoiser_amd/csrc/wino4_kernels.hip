@@ -238,6 +238,48 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    // Tile blocks that lie wholly outside the image (rows 528-543 of a 513-row input; the partner clip of an odd last clip in
+    // pair mode) do no arithmetic: their two waves keep copying their share of every chunk and meet every barrier, so the
+    // other wave of each SIMD has the matrix pipe to itself for that tile.
+    const bool active = ty * REG + 16 * by < p.H && (pair ? 0 : tx * REG + 16 * bx) < p.W && n + (pair ? bx : 0) < p.N;
+    constexpr int DSTR = 256 * 17 + 32;                 // fused 1x1 epilogue: floats per wave, [pixel][17] + 8 of skew per tile row
+    auto dot_sums = [&]() {                             // one thread per pixel adds the 2 x 16 terms of its pixel (fixed order)
+        const int lt = wave * 64 + lane_id();
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int P = k * NT + lt;                  // pixel of the 32x32 tile: block P >> 8, row (P >> 4) & 15, column P & 15
+            const int blk = P >> 8, px = P & 255;
+            const float *s0 = smem + (blk * 2) * DSTR + px * 17 + (px >> 6) * 8;
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sum += s0[i];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sum += s0[DSTR + i];
+            const int gy = ty * REG + 16 * (blk >> 1) + (px >> 4), gx = tx * REG + (pair ? 0 : 16 * (blk & 1)) + (px & 15);
+            const int nn = n + (pair ? (blk & 1) : 0);
+            if (gy < p.H && gx < p.W && nn < p.N) p.dot_out[(((size_t)ct * p.N + nn) * p.H + gy) * p.W + gx] = sum;
+        }
+    };
+    if (LEAN && !active) {                              // (the plain variant's register allocation suffers from this branch: -3 %)
+        for (int c = 0; c + 1 < p.nchunk; ++c) {
+            W4_DMA_BEGIN(c + 1);
+#pragma unroll
+            for (int k = 0; k < HR + UR; ++k) W4_DMA_PIECE(k, (c + 1) & 1);
+            W4_DMA_END();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!(ABL & 8)) __syncthreads();
+        }
+        if (!(ABL & 8)) __syncthreads();                // the last chunk's barrier
+        if constexpr (ABL & 2048) return;
+        __syncthreads();                                // epilogue: exchange blocks written
+        if constexpr (EPI == CONV3X3_RELU_DOT) {
+            __syncthreads();
+            __syncthreads();
+            dot_sums();
+        }
+        return;
+    }
+
     constexpr int abl = ABL;
     for (int c = 0; c < p.nchunk; ++c) {
         const bool more = c + 1 < p.nchunk && !((abl & 1) && c >= 1);
@@ -392,7 +434,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             }
         }
         __syncthreads();                                // every wave has read its partner's exchange block
-        constexpr int DSTR = 256 * 17 + 32;             // floats per wave: [pixel][17] + 8 floats of skew per tile row
         float *dw = smem + wave * DSTR + eq * 8 + eti;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -401,20 +442,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
                 for (int b = 0; b < 4; ++b) dw[((4 * eq + a) * 16 + 4 * r + b) * 17] = yf[r][a][b];
         __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int P = k * NT + wave * 64 + el;      // pixel of the 32x32 tile: block P >> 8, row (P >> 4) & 15, column P & 15
-            const int blk = P >> 8, px = P & 255;
-            const float *s0 = smem + (blk * 2) * DSTR + px * 17 + (px >> 6) * 8;
-            float sum = 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sum += s0[i];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sum += s0[DSTR + i];
-            const int gy = ty * REG + 16 * (blk >> 1) + (px >> 4), gx = tx * REG + (pair ? 0 : 16 * (blk & 1)) + (px & 15);
-            const int nn = n + (pair ? (blk & 1) : 0);
-            if (gy < p.H && gx < p.W && nn < p.N) p.dot_out[(((size_t)ct * p.N + nn) * p.H + gy) * p.W + gx] = sum;
-        }
+        dot_sums();
         return;
     }
     const int nb = n + (pair ? bx : 0);                 // pair mode: the tile blocks of column 1 belong to the next clip
