@@ -117,7 +117,34 @@ __device__ __forceinline__ void at6(float m0, float m1, float m2, float m3, floa
 // (in registers the loop needs, i.e. as scratch spills: measured 0.3 GB of spill traffic per full-resolution launch)
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
-template <int EPI, int ABL = 0>
+// Which of the ten copy pieces of the next chunk goes out behind MFMA group gi (0..17: two passes of nine groups), -1 = none.
+// All placements are equivalent arithmetically; hipcc's schedule of the loop is not (38.6 ... 45.2 ms per batch-64 step over
+// the placements tried, profiles/r02_wino4_placement.txt), so the placement is chosen per epilogue variant by measurement
+// (tools/wino4_placement.sh).
+// W4_PLACE[placement][gi] = piece (0..9) or -1.  0: every other group; 1 / 6 / 2 / 14: two of every three starting at group
+// 0 / 1 / 2 / 3; 3: the first five groups of each pass; 5: all early; 7, 8: three of every four; the rest: irregular.
+__device__ constexpr signed char W4_PLACE[16][18] = {
+    { 0, -1,  1, -1,  2, -1,  3, -1,  4, -1,  5, -1,  6, -1,  7, -1,  8,  9},
+    { 0,  1, -1,  2,  3, -1,  4,  5, -1,  6,  7, -1,  8,  9, -1, -1, -1, -1},
+    {-1, -1,  0,  1, -1,  2,  3, -1,  4,  5, -1,  6,  7, -1,  8,  9, -1, -1},
+    { 0,  1,  2,  3,  4, -1, -1, -1, -1,  5,  6,  7,  8,  9, -1, -1, -1, -1},
+    { 0, -1,  1, -1,  2, -1,  3, -1,  4,  5, -1,  6, -1,  7, -1,  8, -1,  9},
+    { 0,  1,  2,  3,  4,  5,  6,  7,  8,  9, -1, -1, -1, -1, -1, -1, -1, -1},
+    {-1,  0,  1, -1,  2,  3, -1,  4,  5, -1,  6,  7, -1,  8,  9, -1, -1, -1},
+    { 0,  1,  2, -1,  3,  4,  5, -1,  6,  7,  8, -1,  9, -1, -1, -1, -1, -1},
+    {-1,  0,  1,  2, -1,  3,  4,  5, -1,  6,  7,  8, -1,  9, -1, -1, -1, -1},
+    {-1,  0,  1, -1,  2,  3, -1,  4,  5, -1,  6,  7,  8,  9, -1, -1, -1, -1},
+    {-1,  0, -1,  1,  2, -1,  3,  4, -1,  5,  6, -1,  7,  8, -1,  9, -1, -1},
+    {-1,  0,  1, -1,  2,  3,  4, -1,  5, -1,  6,  7, -1,  8,  9, -1, -1, -1},
+    {-1, -1,  0,  1,  2, -1,  3,  4,  5, -1, -1,  6,  7,  8, -1,  9, -1, -1},
+    {-1,  0,  1, -1, -1,  2,  3,  4,  5, -1,  6,  7, -1, -1,  8,  9, -1, -1},
+    {-1, -1, -1,  0,  1, -1,  2,  3, -1,  4,  5, -1,  6,  7, -1,  8,  9, -1},
+    {-1,  0,  1,  2,  3,  4, -1, -1, -1, -1,  5,  6,  7,  8,  9, -1, -1, -1},
+};
+__host__ __device__ constexpr int w4_piece_at(int PL, int gi) { return W4_PLACE[PL & 15][gi]; }
+constexpr int w4_default_placement(int EPI) { return EPI == CONV3X3_RELU_DOT ? 0 : 6; }
+
+template <int EPI, int ABL = 0, int PL = w4_default_placement(EPI)>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino4_conv_f32(const ConvArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];   // the ONLY LDS object (two images)
@@ -347,7 +374,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 W4_LANDED(u[g & 1]);
                 if (g < 8 && !(abl & 16)) W4_LOADU(u[(g + 1) & 1], g + 1);
                 __builtin_amdgcn_sched_barrier(0);
-                if (more && ((9 * h + g) % 2 == 0 || 9 * h + g == 17)) W4_DMA_PIECE((9 * h + g == 17 ? 9 : (9 * h + g) / 2), nb);
+                if (more && w4_piece_at(PL, 9 * h + g) >= 0) W4_DMA_PIECE((w4_piece_at(PL, 9 * h + g) >= 0 ? w4_piece_at(PL, 9 * h + g) : 0), nb);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
@@ -529,6 +556,23 @@ hipError_t launch_wino4_conv(ConvKind kind, const ConvArgs &a, hipStream_t st)
         attr_mask.fetch_or(bit, std::memory_order_release);
     }
 #ifdef ADN_EXPERIMENTS
+    static const int place = []() { const char *e = std::getenv("ADN_W4_PLACE"); return e ? std::atoi(e) : -1; }();
+    if (place >= 0 && !a2.ablate) {
+        const void *f = nullptr;
+        switch (place * 4 + (int)kind) {
+#define W4_PL(n) case n * 4 + 0: f = reinterpret_cast<const void *>(wino4_conv_f32<CONV3X3_RELU, 0, n>); break; \
+                 case n * 4 + 1: f = reinterpret_cast<const void *>(wino4_conv_f32<CONV3X3_RELU_POOL, 0, n>); break; \
+                 case n * 4 + 3: f = reinterpret_cast<const void *>(wino4_conv_f32<CONV3X3_RELU_DOT, 0, n>); break;
+            W4_PL(0) W4_PL(1) W4_PL(2) W4_PL(3) W4_PL(4) W4_PL(5) W4_PL(6) W4_PL(7)
+            W4_PL(8) W4_PL(9) W4_PL(10) W4_PL(11) W4_PL(12) W4_PL(13) W4_PL(14) W4_PL(15)
+#undef W4_PL
+        default: return hipErrorInvalidValue;
+        }
+        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e != hipSuccess) return e;
+        void *args[] = {&a2};
+        return hipLaunchKernel(f, dim3((unsigned)nwg), dim3(NT), args, LDS_BYTES, st);
+    }
     if (a2.ablate) {
         const void *f = nullptr;
         switch (a2.ablate) {
