@@ -320,9 +320,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         f32x2 d[6][5];
         if (!(abl & 2)) {
 #pragma unroll
-            for (int a = 0; a < 6; ++a)
+            for (int ao = 0; ao < 6; ++ao) {
+                // rows 0, 2, 4 first: the first MFMA group's positions (transform-domain row 0) need only those
+                const int a = ao < 3 ? 2 * ao : 2 * ao - 5;
 #pragma unroll
                 for (int k = 0; k < 5; ++k) d[a][k] = *(lds4_cv_f32x2 *)(sA + (a < 4 ? a_lo : a_hi) + (a * RSL + k) * 4);
+            }
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
