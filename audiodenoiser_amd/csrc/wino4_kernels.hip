@@ -142,6 +142,20 @@ __device__ constexpr signed char W4_PLACE[16][18] = {
     {-1,  0,  1,  2,  3,  4, -1, -1, -1, -1,  5,  6,  7,  8,  9, -1, -1, -1},
 };
 __host__ __device__ constexpr int w4_piece_at(int PL, int gi) { return W4_PLACE[PL & 15][gi]; }
+constexpr bool w4_placements_valid()                    // every row places each of the ten pieces exactly once
+{
+    for (int pl = 0; pl < 16; ++pl) {
+        int seen = 0;
+        for (int gi = 0; gi < 18; ++gi)
+            if (W4_PLACE[pl][gi] >= 0) {
+                if (W4_PLACE[pl][gi] > 9 || (seen >> W4_PLACE[pl][gi]) & 1) return false;
+                seen |= 1 << W4_PLACE[pl][gi];
+            }
+        if (seen != 0x3ff) return false;
+    }
+    return true;
+}
+static_assert(w4_placements_valid(), "W4_PLACE: each placement must issue pieces 0..9 exactly once");
 constexpr int w4_default_placement(int EPI) { return EPI == CONV3X3_RELU_DOT ? 0 : 6; }
 
 template <int EPI, int ABL = 0, int PL = w4_default_placement(EPI)>
