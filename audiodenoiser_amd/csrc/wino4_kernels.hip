@@ -112,7 +112,7 @@ __device__ __forceinline__ void at6(float m0, float m1, float m2, float m3, floa
 // ABL: timing experiments (-DADN_EXPERIMENTS builds, ADN_WINO4_ABLATE): 1 no copies after the first chunk, 2 no patch
 // reads / transform, 4 no transform, 8 no barrier, 16 no B-fragment reads, 32 no U copies, 64 no halo copies, 128 every
 // copy reads the zero block, 256 contiguous (L1-resident) stand-in for the halo gather, 2048 no epilogue, 4096 no global
-// stores in the epilogue; results are wrong by design.  0 in production.
+// stores in the epilogue, 8192 first chunk's copies not awaited (prologue latency); results are wrong by design.  0 in production.
 // lane id without the work-item-id register: values derived from threadIdx.x would otherwise have to survive the K loop
 // (in registers the loop needs, i.e. as scratch spills: measured 0.3 GB of spill traffic per full-resolution launch)
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
     for (int k = 0; k < HR; ++k) W4_DMA_PIECE(k, 0);
     W4_DMA_END();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!(ABL & 8192)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // 8192: timing experiment, first chunk not awaited
     __syncthreads();
 
     // Tile blocks that lie wholly outside the image (rows 528-543 of a 513-row input; the partner clip of an odd last clip in
@@ -595,7 +595,7 @@ hipError_t launch_wino4_conv(ConvKind kind, const ConvArgs &a, hipStream_t st)
         switch (a2.ablate) {
 #define W4_ABL(n) case n: f = reinterpret_cast<const void *>(wino4_conv_f32<CONV3X3_RELU, n>); break;
             W4_ABL(1) W4_ABL(2) W4_ABL(4) W4_ABL(8) W4_ABL(16) W4_ABL(9) W4_ABL(18) W4_ABL(19) W4_ABL(27) W4_ABL(32) W4_ABL(64)
-            W4_ABL(128) W4_ABL(256) W4_ABL(2048) W4_ABL(2067) W4_ABL(4096)
+            W4_ABL(128) W4_ABL(256) W4_ABL(2048) W4_ABL(2067) W4_ABL(4096) W4_ABL(8192)
 #undef W4_ABL
         default: return hipErrorInvalidValue;
         }
