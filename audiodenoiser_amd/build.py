@@ -46,12 +46,40 @@ def _sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def _strip_comments(text: str) -> str:
+    """C / C++ source with comments removed and runs of whitespace collapsed (string and character literals kept), so that
+    the digest below identifies the CODE of a build: editing a comment does not orphan profiles/pmc_traffic.json."""
+    out = []
+    i, n = 0, len(text)
+    while i < n:
+        c = text[i]
+        if c in "\"'":                                   # literal: copy verbatim up to the closing quote
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1])
+            i = j + 1
+        elif text.startswith("//", i):
+            j = text.find("\n", i)
+            while j > 0 and text[j - 1] == "\\":             # a line comment continued by a backslash
+                j = text.find("\n", j + 1)
+            i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            out.append(" ")
+            i = n if j < 0 else j + 2
+        else:
+            out.append(c)
+            i += 1
+    return " ".join("".join(out).split())
+
+
 def _digest() -> str:
     h = hashlib.sha256()
     for p in _sources() + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(INCLUDE, "adn.h")]:
         h.update(os.path.basename(p).encode())
-        with open(p, "rb") as f:
-            h.update(f.read())
+        with open(p, "r", encoding="utf-8") as f:
+            h.update(_strip_comments(f.read()).encode())
     h.update(ARCH.encode())
     h.update(" ".join(_extra_flags()).encode())
     h.update(repr(sorted(FILE_FLAGS.items())).encode())

@@ -634,11 +634,9 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void conv_dma(const ConvArgs p)
 // ------------------------------------------------------------------------------------------------
 // First layer: Conv2d(1 -> 64, 3x3, pad 1) + folded BN + ReLU (model.py:11-13 via :56).  HBM-bound
 // (4.4 FLOP/B, write-dominated: 64 output floats per input float).  Vector loads queue behind the same CU's
-// outstanding stores (measured with tools/ubench/first_layer.hip: the per-strip global-load form ran at 2.9 TB/s,
+// outstanding stores (measured with tools/ubench/first_layer.hip: a per-strip global-load form ran at 2.9 TB/s,
 // the same kernel without loads at 5.6), so a workgroup fetches the (FIRST_ROWS+2) x (W+2) input window of its
-// FIRST_ROWS image rows ONCE into LDS and then only stores: 16 lanes share a strip of FIRST_PX pixels, each lane
-// owns 4 output channels (16-byte store for fp32, 8-byte for fp16), reads its 3 x (FIRST_PX+2) window from LDS
-// (a path of its own) and keeps the weights in registers.  Input is always fp32.
+// FIRST_ROWS image rows ONCE into LDS and then only stores.  Input is always fp32.
 // ------------------------------------------------------------------------------------------------
 constexpr int FIRST_ROWS = 8;
 

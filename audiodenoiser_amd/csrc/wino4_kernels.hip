@@ -2,8 +2,9 @@
 //
 // Same role as wino_conv_dma_f32 (wino_kernels.hip) for the 3x3 layers of the reference's DoubleConvLayer
 // (/root/reference/code/model.py:7-20): conv3x3(pad 1) + folded BatchNorm + ReLU (+ MaxPool2d(2), + virtual
-// F.pad/torch.cat of the up path), channel-blocked fp32 in and out (C8, adn_internal.h).  F(4x4,3x3) needs 36 multiplies per 4x4 output tile and
-// input channel instead of 144: 4x fewer matrix-core FLOPs than the direct form, 1.78x fewer than F(2x2,3x3):
+// F.pad/torch.cat of the up path), channel-blocked fp32 in and out (C8, adn_internal.h).  F(4x4,3x3) needs 36 multiplies
+// per 4x4 output tile and input channel instead of 144: 4x fewer matrix-core FLOPs than the direct form, 1.78x fewer than
+// F(2x2,3x3):
 //      Y = A^T [ (G g G^T) .* (B^T d B) ] A        summed over input channels, interpolation points 0, +-1, +-2, inf
 //   U = G g G^T (6x6) is precomputed on the host in double precision (BatchNorm scale folded in);
 //   V = B^T d B is computed in registers from the 6x6 patch of the LDS halo by the wave that consumes it;
@@ -12,8 +13,8 @@
 //   on v_mfma_f32_16x16x4_f32: 16 tiles x 16 couts per MFMA, 36 accumulators (one per position) of identical
 //   layout, so the inverse transform A^T M A is in-lane and a lane's 4x4 output tile holds four max-pool windows.
 // The transforms multiply by 2, 4, 5, 8: results are no longer bit-identical to a direct fp32 sum, the rounding error
-// is ~4x that of F(2x2,3x3) (measured against the reference goldens: 6e-6 of max|y| for the whole network against
-// the 1e-4 bound).
+// is ~4x that of F(2x2,3x3) (measured against the reference goldens: 6.6e-6 of max|y| for the whole network at 513x256
+// against the 1e-4 bound).
 //
 // Workgroup = 8 waves = 32x32 output pixels (2x2 blocks of 4x4 tiles) x 32 output channels, one per CU (144 accumulator
 // registers per wave leave room for two waves per SIMD):
@@ -109,10 +110,6 @@ __device__ __forceinline__ void at6(float m0, float m1, float m2, float m3, floa
     y3 = __builtin_fmaf(8.f, d, b) + m5;
 }
 
-// ABL: timing experiments (-DADN_EXPERIMENTS builds, ADN_WINO4_ABLATE): 1 no copies after the first chunk, 2 no patch
-// reads / transform, 4 no transform, 8 no barrier, 16 no B-fragment reads, 32 no U copies, 64 no halo copies, 128 every
-// copy reads the zero block, 256 contiguous (L1-resident) stand-in for the halo gather, 2048 no epilogue, 4096 no global
-// stores in the epilogue, 8192 first chunk's copies not awaited (prologue latency); results are wrong by design.  0 in production.
 // lane id without the work-item-id register: values derived from threadIdx.x would otherwise have to survive the K loop
 // (in registers the loop needs, i.e. as scratch spills: measured 0.3 GB of spill traffic per full-resolution launch)
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
@@ -158,6 +155,10 @@ constexpr bool w4_placements_valid()                    // every row places each
 static_assert(w4_placements_valid(), "W4_PLACE: each placement must issue pieces 0..9 exactly once");
 constexpr int w4_default_placement(int EPI) { return EPI == CONV3X3_RELU_DOT ? 0 : 6; }
 
+// ABL: timing experiments (-DADN_EXPERIMENTS builds, ADN_WINO4_ABLATE): 1 no copies after the first chunk, 2 no patch
+// reads / transform, 4 no transform, 8 no barrier, 16 no B-fragment reads, 32 no U copies, 64 no halo copies, 128 every
+// copy reads the zero block, 256 contiguous (L1-resident) stand-in for the halo gather, 2048 no epilogue, 4096 no global
+// stores in the epilogue, 8192 first chunk's copies not awaited (prologue latency); results are wrong by design.  0 in production.
 template <int EPI, int ABL = 0, int PL = w4_default_placement(EPI)>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino4_conv_f32(const ConvArgs p)
 {

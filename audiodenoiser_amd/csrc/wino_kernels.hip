@@ -2,9 +2,11 @@
 //
 // Same role as conv_mfma_f32 (conv_kernels.hip) for the 3x3 layers of the reference's DoubleConvLayer
 // (/root/reference/code/model.py:7-20): conv3x3(pad 1) + folded BatchNorm + ReLU (+ MaxPool2d(2), + virtual
-// F.pad/torch.cat of the up path), channel-blocked fp32 in and out (C8, adn_internal.h).  The minimal-filtering algorithm needs 16 multiplies
-// per 2x2 output tile and input channel instead of 36, i.e. 2.25x fewer matrix-core FLOPs, and stays in exact
-// fp32 (transforms are additions and multiplications by 1/2):
+// F.pad/torch.cat of the up path), channel-blocked fp32 in and out (C8, adn_internal.h).  Runs the layers whose image
+// the 32x32-pixel tiles of the F(4x4,3x3) kernel (wino4_kernels.hip) do not fit, the fused-first-layer and split-K forms,
+// and every 3x3 layer with ADN_WINO_TILE=2.  The minimal-filtering algorithm needs 16 multiplies per 2x2 output tile and
+// input channel instead of 36, i.e. 2.25x fewer matrix-core FLOPs, and stays in exact fp32 (transforms are additions and
+// multiplications by 1/2):
 //      Y = A^T [ (G g G^T) .* (B^T d B) ] A        summed over input channels
 //   U = G g G^T is precomputed on the host in double precision (BatchNorm scale folded in);
 //   V = B^T d B is computed in registers from the LDS halo tile by the wave that consumes it;

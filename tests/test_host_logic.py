@@ -440,3 +440,23 @@ def test_profile_summary_demangles_float16_kernel_names():
     assert pmc.FAMILIES["stft_wave_kernel"]("stft_wave_kernel<512, 4, 16, 3, false>")
     assert pmc.FAMILIES["stft_wave_kernel_fit"]("stft_wave_kernel<512, 4, 16, 3, true>")
     assert pmc.short("void adn::(anonymous namespace)::wino_conv_dma_f32<0, 4, 0, 0>(adn::ConvArgs)") == "wino_conv_dma_f32<0, 4, 0, 0>"
+
+
+def test_library_digest_identifies_code_not_comments(tmp_path, monkeypatch):
+    """profiles/pmc_traffic.json is tied to a build by the digest of its sources; comments and whitespace do not count."""
+    from audiodenoiser_amd import build as B
+    src = 'int a = 1; // note\n/* block\n comment */ const char *s = "// kept /* kept */"; char c = \'"\';  // tail \\\ncontinued\nint b = 2;\n'
+    assert B._strip_comments(src) == 'int a = 1; const char *s = "// kept /* kept */"; char c = \'"\'; int b = 2;'
+    csrc = tmp_path / "csrc"
+    inc = tmp_path / "include"
+    csrc.mkdir()
+    inc.mkdir()
+    (inc / "adn.h").write_text("int adn_version(void);\n")
+    (csrc / "k.hip").write_text("// v1\n__global__ void k(float *p) { p[0] = 1.f; }\n")
+    monkeypatch.setattr(B, "CSRC", str(csrc))
+    monkeypatch.setattr(B, "INCLUDE", str(inc))
+    d0 = B._digest()
+    (csrc / "k.hip").write_text("// reworded comment\n\n__global__ void k(float *p)   { p[0] = 1.f; }   /* same code */\n")
+    assert B._digest() == d0
+    (csrc / "k.hip").write_text("__global__ void k(float *p) { p[0] = 2.f; }\n")
+    assert B._digest() != d0
