@@ -66,10 +66,15 @@ __device__ __forceinline__ int xcd_remap4(int b, int nwg)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
 }
 
-__device__ __forceinline__ void dma16(const float *g, float *lds_wave_base)
+// LDS-DMA through a buffer descriptor (buffer_load_dwordx4 ... offen lds): lane l of the wave copies the 16 bytes at
+// descriptor base + voff + soff to lds_wave_base + 16 l.  The range check compares voff with the descriptor's size, and a
+// lane that fails it writes ZEROS into its LDS slot (tools/ubench/buffer_lds_oob.hip): the convolution's zero padding and the
+// pad slots of the LDS layout cost no select against a zero block and no 64-bit address arithmetic -- a copy piece is one
+// scalar add and the instruction.
+constexpr unsigned OOB = 0x80000000u;        // voff of a padding lane (every image handled here is smaller than 2 GB)
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, float *lds_wave_base)
 {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)lds_wave_base, 16, voff, soff, 0, 0);
 }
 
 // B^T x for the points (0, 1, -1, 2, -2, inf), in place:
@@ -199,13 +204,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int gy0 = ty * REG - 1, gx0 = tx * REG - 1;
 
     // U slab of the first chunk: needs no plan, flies under the index arithmetic below
-    const float *wp = static_cast<const float *>(p.wpk) + (size_t)ct * p.nchunk * (USLOTS * 4) + tid * 4;
+    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(static_cast<const float *>(p.wpk)) + (size_t)ct * p.nchunk * (USLOTS * 4), 0,
+        p.nchunk * (USLOTS * 16), 0x00020000);             // the U slabs of this cout tile, chunk after chunk
+    const unsigned uoff = tid * 16;                        // this lane's 16 bytes inside a 512-slot round
+    unsigned usoff = 0;                                    // byte offset of the next chunk's slab
 #pragma unroll
     for (int k = 0; k < UR; ++k)
-        if (k * NT + wave * 64 < USLOTS) dma16(wp + k * NT * 4, smem + (HSLOTS + k * NT + wave * 64) * 4);
+        if (k * NT + wave * 64 < USLOTS) dma16(urs, uoff, usoff + k * NT * 16, smem + (HSLOTS + k * NT + wave * 64) * 4);
 
-    // DMA plan of the halo: slot s = r*NT + tid -> (row, pixel, channel half); offsets into the current source, -1 = zeros
-    int hcur[HR];
+    // DMA plan of the halo: slot s = r*NT + tid -> (row, pixel, channel half); byte offsets into the current source, OOB = zeros
+    unsigned hcur[HR];                                  // byte offsets inside the source image(s), OOB = padding
     auto plan = [&](const ConvSrc &s) {
         // LEAN variants: thread id rebuilt from the lane id and the plan of the second source kept inside the loop (the empty
         // asm stops its hoisting), so that neither survives the K loop in registers
@@ -223,19 +232,27 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             c -= second * (HPX / 2);
             const bool data = row < HP && j < RSL && c < (pair ? HPX / 2 : HP) && n + second < p.N;
             const int y = gy0 + row - s.offY, x = gx0 + c - s.offX;
-            hcur[r] = (data && y >= 0 && y < s.H && x >= 0 && x < s.W) ? (y * s.W + x) * 8 + half * 4 + second * s.C * s.H * s.W : -1;   // C8 layout
+            hcur[r] = (data && y >= 0 && y < s.H && x >= 0 && x < s.W)
+                          ? (unsigned)((y * s.W + x) * 8 + half * 4 + second * s.C * s.H * s.W) * 4u : OOB;   // C8 layout
         }
     };
     plan(p.s0);
-    const float *srcp = static_cast<const float *>(p.s0.ptr) + (size_t)n * p.s0.H * p.s0.W * p.s0.C;   // next chunk's 8-channel block
-    size_t cstr = (size_t)p.s0.H * p.s0.W * 8;         // floats between consecutive channel blocks of the current source
-    const float *zsrc = p.zeros;
+    // descriptor of the current source: the image of clip n (pair mode: clips n, n + 1); soff walks its 8-channel blocks
+    auto src_rsrc = [&](const ConvSrc &s) {
+        const unsigned img = (unsigned)(s.C * s.H * s.W) * 4u;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(static_cast<const float *>(s.ptr)) + (size_t)n * s.H * s.W * s.C, 0,
+                                                 img << pair, 0x00020000);
+    };
+    __amdgpu_buffer_rsrc_t hrs = src_rsrc(p.s0);
+    unsigned hsoff = 0;                                 // byte offset of the next chunk's channel block
+    unsigned cstr = (unsigned)(p.s0.H * p.s0.W) * 32u;  // bytes between consecutive channel blocks of the current source
 
 #define W4_DMA_BEGIN(c)                                                                        \
     do {                                                                                       \
         if ((c) == p.nchunk0) {                       /* wave-uniform: switch to the second source (virtual concat) */ \
-            srcp = static_cast<const float *>(p.s1.ptr) + (size_t)n * p.s1.H * p.s1.W * p.s1.C; \
-            cstr = (size_t)p.s1.H * p.s1.W * 8;                                                \
+            hrs = src_rsrc(p.s1);                                                              \
+            hsoff = 0;                                                                         \
+            cstr = (unsigned)(p.s1.H * p.s1.W) * 32u;                                          \
             plan(p.s1);                                                                        \
         }                                                                                      \
     } while (0)
@@ -244,15 +261,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     do {                                                                                       \
         float *dst_ = smem + (buf) * IMG + ((k) * NT + wave * 64) * 4;                         \
         if ((k) < HR) {                                                                        \
-            if (ABL & 256) dma16(srcp + (((k) * NT + tid) * 4) % 8192, dst_);          /* contiguous stand-in for the halo gather */ \
-            else if (!(ABL & 64)) dma16((hcur[(k) < HR ? (k) : 0] >= 0 && !(ABL & 128)) ? srcp + hcur[(k) < HR ? (k) : 0] : zsrc, dst_); \
+            if (ABL & 256) dma16(hrs, (((k) * NT + tid) * 16) % 32768, hsoff, dst_);   /* contiguous stand-in for the halo gather */ \
+            else if (!(ABL & 64)) dma16(hrs, (ABL & 128) ? OOB : hcur[(k) < HR ? (k) : 0], hsoff, dst_); \
         } else if (((k) - HR) * NT + wave * 64 < USLOTS && !(ABL & 32))                        \
-            dma16((ABL & 128) ? zsrc : wp + ((k) - HR) * NT * 4, dst_);                        \
+            dma16(urs, (ABL & 128) ? OOB : uoff, usoff + ((k) - HR) * NT * 16, dst_);          \
     } while (0)
 #define W4_DMA_END()                                                                           \
     do {                                                                                       \
-        srcp += cstr;                                                                          \
-        wp += USLOTS * 4;                                                                      \
+        hsoff += cstr;                                                                         \
+        usoff += USLOTS * 16;                                                                  \
     } while (0)
 
 
@@ -535,6 +552,9 @@ bool wino4_applicable(ConvKind kind, const ConvArgs &a, bool force)
     if (kind != CONV3X3_RELU && kind != CONV3X3_RELU_POOL && kind != CONV3X3_RELU_DOT) return false;
     if (kind == CONV3X3_RELU_DOT && (!a.dotw || !a.dot_out)) return false;
     if (a.firstw || a.ksplit > 1 || (a.Cout & 31) || a.nchunk < 1) return false;
+    // the copies address a source image (two in pair mode) through a buffer descriptor with 31-bit byte offsets
+    const long lim = (1L << 31) >> (a.W <= 16 ? 1 : 0);
+    if ((long)a.s0.C * a.s0.H * a.s0.W * 4 >= lim || (long)a.s1.C * a.s1.H * a.s1.W * 4 >= lim) return false;
     // images at most 16 pixels wide run in pair mode: a tile covers 32 rows x 16 columns of each of two clips
     const long th = (a.H + REG - 1) / REG, tw = (a.W + REG - 1) / REG;
     const long tiled = a.W <= 16 ? th * REG * 16 : th * tw * REG * REG;
@@ -543,7 +563,7 @@ bool wino4_applicable(ConvKind kind, const ConvArgs &a, bool force)
 
 hipError_t launch_wino4_conv(ConvKind kind, const ConvArgs &a, hipStream_t st)
 {
-    if (!wino4_applicable(kind, a, true) || !a.zeros) return hipErrorInvalidValue;
+    if (!wino4_applicable(kind, a, true)) return hipErrorInvalidValue;
     ConvArgs a2 = a;
     a2.tilesY = (a.H + REG - 1) / REG;
     a2.tilesX = (a.W + REG - 1) / REG;
