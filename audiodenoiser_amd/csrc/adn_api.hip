@@ -234,7 +234,8 @@ struct Plan {
 bool make_plan(int N, int F, int T, bool f16, Plan &p)
 {
     // T <= 4094: the first layer stages 10 rows x (T+2) floats in LDS; F*T*64 elements per image must index in int32
-    if (N < 1 || F < 16 || T < 16 || T > 4094 || (long)F * T > (1L << 24)) return false;
+    // F*T < 2^24: a 64-channel fp32 image stays below 4 GB, the range of the buffer descriptors the copy kernels address it with
+    if (N < 1 || F < 16 || T < 16 || T > 4094 || (long)F * T >= (1L << 24)) return false;
     p.N = N;
     p.H[0] = F;
     p.W[0] = T;
@@ -338,7 +339,7 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
 {
     if (!h || !x || !y) return fail(ADN_ERR_INVALID, "adn_unet_forward: null handle/x/y");
     Plan p;
-    if (!make_plan(N, F, T, h->f16, p)) return fail(ADN_ERR_INVALID, "adn_unet_forward: need N>=1, F,T>=16, T<=4094 and F*T<=2^24");
+    if (!make_plan(N, F, T, h->f16, p)) return fail(ADN_ERR_INVALID, "adn_unet_forward: need N>=1, F,T>=16, T<=4094 and F*T<2^24");
     if (!workspace || ws_bytes < p.total)
         return fail(ADN_ERR_WORKSPACE, "adn_unet_forward: workspace too small (see adn_unet_workspace_bytes)");
     // the activation buffers are carved out of the workspace in 256-byte granules and read with 16-byte LDS-DMA /
@@ -708,7 +709,7 @@ int adn_unet_workspace_bytes(const adn_unet *h, int N, int F, int T, size_t *byt
 {
     if (!bytes) return fail(ADN_ERR_INVALID, "adn_unet_workspace_bytes: null");
     Plan p;
-    if (!make_plan(N, F, T, h ? h->f16 : false, p)) return fail(ADN_ERR_INVALID, "adn_unet_workspace_bytes: need N>=1, F,T>=16, T<=4094 and F*T<=2^24");
+    if (!make_plan(N, F, T, h ? h->f16 : false, p)) return fail(ADN_ERR_INVALID, "adn_unet_workspace_bytes: need N>=1, F,T>=16, T<=4094 and F*T<2^24");
     *bytes = p.total;
     return ADN_OK;
 }

@@ -22,6 +22,24 @@ __host__ __device__ __forceinline__ long act_off(int C, long HW, long pix, int c
     return ((long)(c / B) * HW + pix) * B + (c % B);
 }
 
+// LDS-DMA through a buffer descriptor (buffer_load_dwordx4 ... offen lds): lane l of the wave copies the 16 bytes at
+// descriptor base + voff + soff to lds_wave_base + 16 l.  The range check compares voff with the descriptor's size, and a
+// lane that fails it writes ZEROS into its LDS slot (tools/ubench/buffer_lds_oob.hip): the convolutions' zero padding and the
+// pad slots of the LDS layouts cost no select against a zero block and no 64-bit address arithmetic -- a copy piece is one
+// scalar add and the instruction.  ADN_DMA_OOB: voff of a padding lane (every image is smaller than that: F*T < 2^24).
+#ifdef __HIPCC__
+constexpr unsigned ADN_DMA_OOB = 0xfffffff0u;
+__device__ __forceinline__ void dma16_buf(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, float *lds_wave_base)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)lds_wave_base, 16, voff, soff, 0, 0);
+}
+// descriptor over `bytes` bytes at `base` (both wave-uniform)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dma_rsrc(const void *base, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
+}
+#endif
+
 // One activation source of a convolution (fp32 or fp16 storage, decided by the launcher).  (offY, offX) is
 // the zero-pad placed above / left of the tensor when it is aligned to the output domain (UpSampleLayer's F.pad,
 // reference model.py:44-47).

@@ -458,7 +458,7 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs &p, f32x16 (
 //   LDS image = consecutive 16-byte slots; wave-instruction k of a copy fills slots [k*NT + 64*wave, +64):
 //     A (halo): KG == 1: row = PW pixels x 2 slots + ONE pad slot per row (conflict-free ds_read_b128: a read group holds
 //               two tile rows, whose bases then differ by 4 dwords mod 8);  KG > 1: pixel = 2*KG slots + one pad slot.
-//               Pad and out-of-image slots are copied from a 16-byte block of zeros (the convolution's zero padding).
+//               Pad and out-of-image slots are lanes whose buffer offset is out of range: the copy writes zeros there.
 //               The A part is padded to a multiple of 64 slots so that every wave-instruction is wholly A or wholly B.
 //     B (weights): the packed slab of the chunk, a linear copy.
 // ------------------------------------------------------------------------------------------------
@@ -479,12 +479,6 @@ struct DmaCfg {
     static constexpr size_t LDS_BYTES = (size_t)2 * SLOTS * 16;
     static_assert(B_SLOTS % 64 == 0, "weight slab must be a whole number of wave copies");
 };
-
-__device__ __forceinline__ void conv_dma16(const void *g, float *lds_wave_base)
-{
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
-}
 
 template <typename T, int TH, int BN, int WM, int WN, int TAPS, int KG, int EPI, int WPE>
 __global__ __launch_bounds__(64 * WM * WN, WPE) void conv_dma(const ConvArgs p)
@@ -516,8 +510,9 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void conv_dma(const ConvArgs p)
     const int n = lid / p.tilesY;
     const int gy0 = ty * TH - HALO, gx0 = tx * TW - HALO;
 
-    // ---- DMA plan (fixed over the chunk loop): halo slot s = r*NT + tid -> source element offset, -1 = zeros ----
-    int hcur[A_ROUNDS], hsec[A_ROUNDS];
+    // ---- DMA plan (fixed over the chunk loop): halo slot s = r*NT + tid -> byte offset inside the source image, ADN_DMA_OOB =
+    // zeros (copies go through buffer descriptors: dma16_buf, adn_internal.h) ----
+    unsigned hcur[A_ROUNDS], hsec[A_ROUNDS];
 #pragma unroll
     for (int r = 0; r < A_ROUNDS; ++r) {
         const int s = r * NT + tid;
@@ -527,24 +522,28 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void conv_dma(const ConvArgs p)
         const int gy = gy0 + row, gx = gx0 + pix;
         const int y0 = gy - p.s0.offY, x0 = gx - p.s0.offX;
         hcur[r] = (data && y0 >= 0 && y0 < p.s0.H && x0 >= 0 && x0 < p.s0.W)
-                      ? (int)act_off<T>(p.s0.C, (long)p.s0.H * p.s0.W, y0 * p.s0.W + x0, q * EPV) : -1;
+                      ? (unsigned)act_off<T>(p.s0.C, (long)p.s0.H * p.s0.W, y0 * p.s0.W + x0, q * EPV) * (unsigned)sizeof(T) : ADN_DMA_OOB;
         const int y1 = gy - p.s1.offY, x1 = gx - p.s1.offX;
         hsec[r] = (data && y1 >= 0 && y1 < p.s1.H && x1 >= 0 && x1 < p.s1.W)
-                      ? (int)act_off<T>(p.s1.C, (long)p.s1.H * p.s1.W, y1 * p.s1.W + x1, q * EPV) : -1;
+                      ? (unsigned)act_off<T>(p.s1.C, (long)p.s1.H * p.s1.W, y1 * p.s1.W + x1, q * EPV) * (unsigned)sizeof(T) : ADN_DMA_OOB;
     }
-    const T *srcp = static_cast<const T *>(p.s0.ptr) + (size_t)n * p.s0.H * p.s0.W * p.s0.C;   // next chunk's channels
-    const T *base1 = static_cast<const T *>(p.s1.ptr) + (size_t)n * p.s1.H * p.s1.W * p.s1.C;
-    // elements from one K-chunk to the next in the current source: KG channel blocks of the blocked layout
-    size_t cstr = (size_t)KG * p.s0.H * p.s0.W * ACT_BLOCK<T>;
-    const size_t cstr1 = (size_t)KG * p.s1.H * p.s1.W * ACT_BLOCK<T>;
-    const float *wp = static_cast<const float *>(p.wpk) + (size_t)ct * p.nchunk * B_DW;            // next chunk's slab
-    const float *zsrc = p.zeros;
+    // descriptors: the current source image of clip n (its K-chunks are `cstr` bytes apart) and the weight slabs of this column tile
+    auto src_rsrc = [&](const ConvSrc &s) {
+        return dma_rsrc(static_cast<const T *>(s.ptr) + (size_t)n * s.H * s.W * s.C, (unsigned)((size_t)s.C * s.H * s.W * sizeof(T)));
+    };
+    __amdgpu_buffer_rsrc_t hrs = src_rsrc(p.s0);
+    const __amdgpu_buffer_rsrc_t wrs = dma_rsrc(static_cast<const float *>(p.wpk) + (size_t)ct * p.nchunk * B_DW,
+                                                (unsigned)((size_t)p.nchunk * B_DW * 4));
+    unsigned cstr = (unsigned)((size_t)KG * p.s0.H * p.s0.W * ACT_BLOCK<T> * sizeof(T));
+    unsigned hsoff = 0, wsoff = 0;                      // byte offsets of the next chunk inside the source image / the slabs
+    const unsigned loff = lane * 16;
 
     // copy of chunk `c` into image `buf`: NPIECE wave-instructions per thread
     auto dma_chunk = [&](int c, int buf) {
         if (c == p.nchunk0) {                          // wave-uniform: switch to the second source (virtual concat)
-            srcp = base1;
-            cstr = cstr1;
+            hrs = src_rsrc(p.s1);
+            hsoff = 0;
+            cstr = (unsigned)((size_t)KG * p.s1.H * p.s1.W * ACT_BLOCK<T> * sizeof(T));
 #pragma unroll
             for (int r = 0; r < A_ROUNDS; ++r) hcur[r] = hsec[r];
         }
@@ -554,15 +553,11 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void conv_dma(const ConvArgs p)
             const int sb = k * NT + wave * 64;          // first slot of this wave-instruction (uniform)
             if (sb >= SLOTS) continue;                   // tail of the last piece
             float *dst = img + sb * 4;
-            if (k < A_ROUNDS && sb < A_SLOTS) {
-                const int off = hcur[k < A_ROUNDS ? k : 0];
-                conv_dma16(off >= 0 ? static_cast<const void *>(srcp + off) : static_cast<const void *>(zsrc), dst);
-            } else {
-                conv_dma16(wp + (size_t)(sb - A_SLOTS + lane) * 4, dst);
-            }
+            if (k < A_ROUNDS && sb < A_SLOTS) dma16_buf(hrs, hcur[k < A_ROUNDS ? k : 0], hsoff, dst);
+            else dma16_buf(wrs, loff, wsoff + (unsigned)(sb - A_SLOTS) * 16u, dst);
         }
-        srcp += cstr;
-        wp += B_DW;
+        hsoff += cstr;
+        wsoff += B_DW * 4;
     };
 
     float bias_r[NB];
@@ -783,7 +778,7 @@ hipError_t launch_dma_cfg(const ConvArgs &a, hipStream_t st)
 {
     using C = DmaCfg<T, TH, BN, WM, WN, TAPS, KG>;
     const long nwg = (long)a.N * a.tilesY * a.tilesX * a.nct;
-    if (nwg <= 0 || nwg > 0x7fffffffL || !a.zeros) return hipErrorInvalidValue;
+    if (nwg <= 0 || nwg > 0x7fffffffL) return hipErrorInvalidValue;
     auto kern = conv_dma<T, TH, BN, WM, WN, TAPS, KG, EPI, WPE>;
     if (C::LDS_BYTES > 64 * 1024) {
         // the attribute is per device: remember which devices of this process have it

@@ -66,15 +66,11 @@ __device__ __forceinline__ int xcd_remap4(int b, int nwg)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
 }
 
-// LDS-DMA through a buffer descriptor (buffer_load_dwordx4 ... offen lds): lane l of the wave copies the 16 bytes at
-// descriptor base + voff + soff to lds_wave_base + 16 l.  The range check compares voff with the descriptor's size, and a
-// lane that fails it writes ZEROS into its LDS slot (tools/ubench/buffer_lds_oob.hip): the convolution's zero padding and the
-// pad slots of the LDS layout cost no select against a zero block and no 64-bit address arithmetic -- a copy piece is one
-// scalar add and the instruction.
-constexpr unsigned OOB = 0x80000000u;        // voff of a padding lane (every image handled here is smaller than 2 GB)
+// copies: LDS-DMA through buffer descriptors, padding lanes out of range (dma16_buf, adn_internal.h)
+constexpr unsigned OOB = ADN_DMA_OOB;
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, float *lds_wave_base)
 {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)lds_wave_base, 16, voff, soff, 0, 0);
+    dma16_buf(rsrc, voff, soff, lds_wave_base);
 }
 
 // B^T x for the points (0, 1, -1, 2, -2, inf), in place:
@@ -552,9 +548,6 @@ bool wino4_applicable(ConvKind kind, const ConvArgs &a, bool force)
     if (kind != CONV3X3_RELU && kind != CONV3X3_RELU_POOL && kind != CONV3X3_RELU_DOT) return false;
     if (kind == CONV3X3_RELU_DOT && (!a.dotw || !a.dot_out)) return false;
     if (a.firstw || a.ksplit > 1 || (a.Cout & 31) || a.nchunk < 1) return false;
-    // the copies address a source image (two in pair mode) through a buffer descriptor with 31-bit byte offsets
-    const long lim = (1L << 31) >> (a.W <= 16 ? 1 : 0);
-    if ((long)a.s0.C * a.s0.H * a.s0.W * 4 >= lim || (long)a.s1.C * a.s1.H * a.s1.W * 4 >= lim) return false;
     // images at most 16 pixels wide run in pair mode: a tile covers 32 rows x 16 columns of each of two clips
     const long th = (a.H + REG - 1) / REG, tw = (a.W + REG - 1) / REG;
     const long tiled = a.W <= 16 ? th * REG * 16 : th * tw * REG * REG;

@@ -74,7 +74,7 @@ int adn_unet_workspace_bytes(const adn_unet *handle, int N, int F, int T, size_t
 
 /* y(N,1,F,T) = UNet(x(N,1,F,T)), eval-mode semantics (BatchNorm uses running statistics), fp32.
  * x, y, workspace: device memory on the handle's device.  F,T >= 16 (four 2x poolings). */
-/* Shape limits: N >= 1, F >= 16, 16 <= T <= 4094, F*T <= 2^24 (ADN_ERR_INVALID otherwise). */
+/* Shape limits: N >= 1, F >= 16, 16 <= T <= 4094, F*T < 2^24 (ADN_ERR_INVALID otherwise). */
 int adn_unet_forward(adn_unet *handle, const float *x, float *y, int N, int F, int T,
                      void *workspace, size_t workspace_bytes, void *stream);
 
