@@ -63,11 +63,7 @@ __device__ __forceinline__ int wino_xcd_remap(int b, int nwg)
 // two read layouts gained 3.5 % at 15 % LDS load) -- not the synchronisation form (split barrier, woven transform,
 // wave priorities and start stagger all measured within +-1 %).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void dma16(const float *g, float *lds_wave_base)
-{
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
-}
+// (the copies go through buffer descriptors, dma16_buf in adn_internal.h: padding lanes are out of range and write zeros)
 
 // Geometry of the LDS-DMA kernel for NW waves (4: 16x16 px, two workgroups per CU; 8: 16x32 px, one per CU).
 // The 8-wave tile halves the bytes staged per MFMA (U slab shared by twice the pixels): the kernel is bound by
@@ -134,9 +130,12 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
     const int gy0 = ty * WT - 1, gx0 = tx * G::TPW - 1;
 
     // The U slab of the first chunk needs no halo plan: its copy starts here and flies under the index arithmetic below.
-    const float *wp = static_cast<const float *>(p.wpk) + ((size_t)ct * p.nchunk + c0) * 4096 + tid * 4;
+    const __amdgpu_buffer_rsrc_t urs = dma_rsrc(static_cast<const float *>(p.wpk) + (size_t)ct * p.nchunk * 4096,
+                                                (unsigned)p.nchunk * 16384u);      // the U slabs of this cout tile
+    const unsigned uoff = tid * 16;
+    unsigned usoff = (unsigned)c0 * 16384u;                                         // next chunk's slab
 #pragma unroll
-    for (int k = HR; k < HR + UR; ++k) dma16(wp + (k - HR) * NT * 4, smem + wave * 256 + k * NT * 4);
+    for (int k = HR; k < HR + UR; ++k) dma16_buf(urs, uoff, usoff + (k - HR) * NT * 16, smem + wave * 256 + k * NT * 4);
 
     // ---- DMA plan: halo slot s = r*NT + tid  ->  (row, pixel, 16-byte part) ----
     // hcur = offsets into the source of the NEXT chunk to copy; hsec = offsets into the second source (virtual
@@ -154,9 +153,10 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
         const bool data = s < G::HUSED && !(NW == 4 && k == 16) && pix < G::HW;
         const int gy = gy0 + row, gx = gx0 + pix;
         const int y0 = gy - p.s0.offY, x0 = gx - p.s0.offX;
-        hcur[r] = (data && y0 >= 0 && y0 < p.s0.H && x0 >= 0 && x0 < p.s0.W) ? (y0 * p.s0.W + x0) * 8 + part * 4 : -1;   // C8 layout
+        // byte offsets inside the source image (C8 layout), ADN_DMA_OOB = padding (the copy writes zeros)
+        hcur[r] = (data && y0 >= 0 && y0 < p.s0.H && x0 >= 0 && x0 < p.s0.W) ? ((y0 * p.s0.W + x0) * 8 + part * 4) * 4 : (int)ADN_DMA_OOB;
         const int y1 = gy - p.s1.offY, x1 = gx - p.s1.offX;
-        hsec[r] = (data && y1 >= 0 && y1 < p.s1.H && x1 >= 0 && x1 < p.s1.W) ? (y1 * p.s1.W + x1) * 8 + part * 4 : -1;
+        hsec[r] = (data && y1 >= 0 && y1 < p.s1.H && x1 >= 0 && x1 < p.s1.W) ? ((y1 * p.s1.W + x1) * 8 + part * 4) * 4 : (int)ADN_DMA_OOB;
     }
     if constexpr (SRC == 1) {
         // plan of the fused first layer: hcur = index of the slot's 3x3 input window in the LDS copy (-1: the halo pixel
@@ -175,22 +175,25 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
     }
     float *const sX = smem + 2 * DBUF;                 // SRC == 1: input window [20][20], then weights [9][64] + bias [64]
     float *const sW = sX + XWIN;
-    const float *srcp = static_cast<const float *>(p.s0.ptr) + (size_t)n * p.s0.H * p.s0.W * p.s0.C;   // next chunk's channels
-    const float *base1 = static_cast<const float *>(p.s1.ptr) + (size_t)n * p.s1.H * p.s1.W * p.s1.C;
-    // floats between consecutive 8-channel blocks (= K-chunks) of the current source (C8 layout, adn_internal.h)
-    size_t cstr = (size_t)p.s0.H * p.s0.W * 8;
-    const size_t cstr1 = (size_t)p.s1.H * p.s1.W * 8;
+    // descriptor of the current source (the image of clip n) and the byte offset of the next chunk's 8-channel block in it
+    auto src_rsrc = [&](const ConvSrc &s) {
+        return dma_rsrc(static_cast<const float *>(s.ptr) + (size_t)n * s.H * s.W * s.C, (unsigned)(s.C * s.H * s.W) * 4u);
+    };
+    __amdgpu_buffer_rsrc_t hrs = src_rsrc(p.s0);
+    unsigned cstr = (unsigned)(p.s0.H * p.s0.W) * 32u;
+    const unsigned cstr1 = (unsigned)(p.s1.H * p.s1.W) * 32u;
+    unsigned hsoff = 0;
     if (SPLIT) {
         if (c0 >= p.nchunk0) {                            // the slice starts inside the second source (virtual concat)
-            srcp = base1 + (size_t)(c0 - p.nchunk0) * cstr1;
+            hrs = src_rsrc(p.s1);
+            hsoff = (unsigned)(c0 - p.nchunk0) * cstr1;
             cstr = cstr1;
 #pragma unroll
             for (int r = 0; r < HR; ++r) hcur[r] = hsec[r];
         } else {
-            srcp += (size_t)c0 * cstr;
+            hsoff = (unsigned)c0 * cstr;
         }
     }
-    const float *zsrc = p.zeros;
 
     // fused first layer: halo slot k of chunk `fc` -> image `buf` (what the LDS-DMA would have copied there)
     int fchunk = c0;                                   // SRC == 1: chunk the next staged halo belongs to
@@ -216,7 +219,8 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
     do {                                                                                       \
         if constexpr (SRC == 0) {                                                              \
         if ((c) == p.nchunk0) {                       /* wave-uniform: switch to the second source */ \
-            srcp = base1;                                                                      \
+            hrs = src_rsrc(p.s1);                                                              \
+            hsoff = 0;                                                                         \
             cstr = cstr1;                                                                      \
             _Pragma("unroll") for (int r = 0; r < HR; ++r) hcur[r] = hsec[r];                  \
         }                                                                                      \
@@ -228,13 +232,13 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
         float *dst_ = smem + (buf) * DBUF + wave * 256 + (k) * NT * 4;                         \
         if ((k) < HR) {                                                                        \
             if constexpr (SRC == 1) first_piece((k) < HR ? (k) : 0, (buf));                    \
-            else dma16(hcur[(k) < HR ? (k) : 0] >= 0 ? srcp + hcur[(k) < HR ? (k) : 0] : zsrc, dst_); \
-        } else dma16(wp + ((k) - HR) * NT * 4, dst_);                                          \
+            else dma16_buf(hrs, (unsigned)hcur[(k) < HR ? (k) : 0], hsoff, dst_);              \
+        } else dma16_buf(urs, uoff, usoff + ((k) - HR) * NT * 16, dst_);                       \
     } while (0)
 #define ADN_DMA_END()                                                                          \
     do {                                                                                       \
-        srcp += cstr;                                                                          \
-        wp += 4096;                                                                            \
+        hsoff += cstr;                                                                         \
+        usoff += 16384;                                                                        \
         ++fchunk;                                                                              \
     } while (0)
 #define ADN_DMA(c, buf)                                                                        \
@@ -564,7 +568,6 @@ hipError_t launch_wino_dma_n(ConvKind kind, const ConvArgs &a, hipStream_t st)
     const long ptiles = (long)a2.N * a2.tilesY * a2.tilesX;
     const long nwg = ((ptiles + gp - 1) / gp) * gp * a2.nct;
     if (nwg <= 0 || nwg > 0x7fffffffL) return hipErrorInvalidValue;
-    if (!a2.zeros) return hipErrorInvalidValue;
     a2.ablate = 0;
 #ifdef ADN_EXPERIMENTS
     { const char *ab = std::getenv("ADN_WINO_ABLATE"); a2.ablate = ab ? std::atoi(ab) : 0; }   // timing experiments only
