@@ -42,6 +42,10 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int TW = 16;       // tile width (pixels)
+// transposed convolution: k-groups (32 bytes of channels each) per chunk and workgroups per CU the kernel is built for: two
+// k-groups keep the two LDS images at 37 KB, so that four workgroups per CU overlap each other's short K loops (4-32 chunks),
+// prologues and epilogues (fp32: 4.50 -> 4.20 ms per forward against four k-groups at two workgroups per CU)
+constexpr int CONVT_KG = 2, CONVT_WPE = 4;
 
 template <typename T> struct Elem;
 template <> struct Elem<float> { static constexpr int EPV = 4; };       // elements per 16-byte vector
@@ -313,7 +317,9 @@ template <typename T> struct Piece;
 template <> struct Piece<float> { typedef f32x4 type; };
 template <> struct Piece<_Float16> { typedef f16x8 type; };
 
-template <typename T, int TH, int BN, int WM, int WN, int EPI>
+// HALVES = 2 (transposed convolution only): the tile is staged and stored in two halves of TH/2 rows (the waves of tile-row
+// half hf write, everyone stores), so that the staging tile fits a smaller LDS allocation (more workgroups per CU).
+template <typename T, int TH, int BN, int WM, int WN, int EPI, int HALVES = 1>
 __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs &p, f32x16 (&acc)[TH * TW / 32 / WM][BN / 32 / WN],
                                                      const float (&bias_r)[BN / 32 / WN], float *smem, int tid, int lane,
                                                      int wave, int ct, int n, int ty, int tx)
@@ -326,15 +332,20 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs &p, f32x16 (
     const int wm = wave / WN, wn = wave % WN;
     const int hh = lane >> 5, l31 = lane & 31;
     T *stage = reinterpret_cast<T *>(smem);
+    static_assert(HALVES == 1 || (EPI == CONVT2X2 && HALVES == 2 && WM == 2 && TH % 2 == 0), "two-half staging: convT, WM = 2");
 
+#pragma unroll
+    for (int hf = 0; hf < HALVES; ++hf) {
     // ---- phase 1: accumulators (+ bias, ReLU) -> LDS tile [pixel][channel] ----
+    if (HALVES == 1 || wm == hf) {
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         const int col = (wn * NB + j) * 32 + l31;          // channel inside the tile
         const float bv = bias_r[j];
 #pragma unroll
         for (int i = 0; i < MB; ++i) {
-            const int pix0 = (wm * MB + i) * 32 + 4 * hh;  // tile pixel of register r: pix0 + (r&3) + 8*(r>>2)
+            // tile pixel of register r: pix0 + (r&3) + 8*(r>>2) (two-half staging: relative to the half's first pixel)
+            const int pix0 = ((HALVES == 1 ? wm * MB : 0) + i) * 32 + 4 * hh;
             float v[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -360,6 +371,7 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs &p, f32x16 (
             }
         }
     }
+    }
     __syncthreads();
 
     // ---- phase 2: 16-byte pieces, LDS -> global ----
@@ -376,15 +388,17 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs &p, f32x16 (
         T *ob = outp + (size_t)n * Ho * Wo * p.Cout + (size_t)(NBLK * cg) * bstr;
         const int gxl = lane >> 2, dj = (lane >> 1) & 1, half = lane & 1;
         const int gx = tx * TW + gxl;
+        constexpr int THH = TH / HALVES;                                         // tile rows per staging pass
 #pragma unroll
-        for (int it = 0; it < NBLK * TH / (NT / 64); ++it) {
-            const int run = it * (NT / 64) + wave;                               // (channel block, tile row)
-            const int b8 = run / TH, py = run - b8 * TH;
-            const int gy = ty * TH + py;
+        for (int it = 0; it < NBLK * THH / (NT / 64); ++it) {
+            const int run = it * (NT / 64) + wave;                               // (channel block, tile row of this pass)
+            const int b8 = run / THH, py = run - b8 * THH;
+            const int gy = ty * TH + hf * THH + py;
             const piece_t val = *reinterpret_cast<const piece_t *>(stage + (py * TW + gxl) * RS + dj * 64 + b8 * BE + half * EPP);
             if (gy < p.H && gx < p.W)
                 *reinterpret_cast<piece_t *>(ob + b8 * bstr + ((size_t)(2 * gy + di) * Wo + 2 * gx + dj) * BE + half * EPP) = val;
         }
+        if (HALVES > 1 && hf + 1 < HALVES) __syncthreads();                      // the stores of this half have read the tile
     } else if constexpr (EPI == CONV3X3_RELU_DOT) {
         // Fused last layer (model.py:91,93): the workgroup holds all BN = Cout channels of its pixels, so the 1x1
         // convolution is finished here: each lane dots its 16-byte piece with the matching weights, the PPR lanes of a
@@ -447,6 +461,7 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs &p, f32x16 (
             }
         }
     }
+    }   // hf
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -619,8 +634,10 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void conv_dma(const ConvArgs p)
     // fp16: LDS-staged 16-byte stores (2-byte stores per lane otherwise).  fp32 transposed convolutions (C8 layout): staged
     // too -- a lane's direct stores would be 4 bytes into 32-byte segments, the staged form writes 1 KB runs.
     if constexpr (sizeof(T) == 2 || EPI == CONVT2X2) {
-        static_assert((size_t)TH * TW * (BN + 16 / sizeof(T)) * sizeof(T) <= C::LDS_BYTES, "staging tile must fit the two images");
-        conv_epilogue_staged<T, TH, BN, WM, WN, EPI>(p, acc, bias_r, smem, tid, lane, wave, ct, n, ty, tx);
+        constexpr size_t tile = (size_t)TH * TW * (BN + 16 / sizeof(T)) * sizeof(T);
+        constexpr int HALVES = tile <= C::LDS_BYTES ? 1 : 2;
+        static_assert(tile / HALVES <= C::LDS_BYTES, "staging tile (or half of it) must fit the two images");
+        conv_epilogue_staged<T, TH, BN, WM, WN, EPI, HALVES>(p, acc, bias_r, smem, tid, lane, wave, ct, n, ty, tx);
     } else {
         conv_epilogue<T, TH, BN, WM, WN, EPI>(p, acc, bias_r, lane, wave, ct, n, ty, tx);
     }
@@ -816,8 +833,8 @@ hipError_t launch_conv_mfma_t(ConvKind kind, const ConvArgs &a, hipStream_t st)
         // bound by the bytes staged per FLOP: LDS-DMA staging, and 8-wave workgroups on 32x16-pixel tiles x 64 couts
         // (132 staged bytes per MFMA; 16x16 px x 128 couts would be 164), two workgroups per CU.
         if (kind == CONVT2X2) {
-            if (staging_regs()) return launch_cfg<T, 8, 128, 2, 2, 1, 4, CONVT2X2>(a, st);
-            return launch_dma_cfg<T, 8, 128, 2, 2, 1, 4, CONVT2X2, 2>(a, st);
+            if (staging_regs()) return launch_cfg<T, 8, 128, 2, 2, 1, CONVT_KG, CONVT2X2>(a, st);
+            return launch_dma_cfg<T, 8, 128, 2, 2, 1, CONVT_KG, CONVT2X2, CONVT_WPE>(a, st);
         }
         if (staging_regs()) {
             if (kind == CONV3X3_RELU_DOT) return hipErrorInvalidValue;
@@ -833,8 +850,8 @@ hipError_t launch_conv_mfma_t(ConvKind kind, const ConvArgs &a, hipStream_t st)
     } else {
         if (kind == CONV3X3_RELU_DOT) return hipErrorInvalidValue;     // fp32: only the Winograd kernel fuses the last layer
         if (kind == CONVT2X2) {
-            if (staging_regs()) return launch_cfg<T, 8, 128, 2, 2, 1, 4, CONVT2X2>(a, st);
-            return launch_dma_cfg<T, 8, 128, 2, 2, 1, 4, CONVT2X2, 2>(a, st);
+            if (staging_regs()) return launch_cfg<T, 8, 128, 2, 2, 1, CONVT_KG, CONVT2X2>(a, st);
+            return launch_dma_cfg<T, 8, 128, 2, 2, 1, CONVT_KG, CONVT2X2, CONVT_WPE>(a, st);
         }
         if (a.Cout == 64) {
             if (kind == CONV3X3_RELU_POOL) return launch_cfg<T, 16, 64, 4, 1, 9, 1, CONV3X3_RELU_POOL>(a, st);
@@ -851,7 +868,7 @@ hipError_t launch_conv_mfma_t(ConvKind kind, const ConvArgs &a, hipStream_t st)
 ConvGeom conv_geom(ConvKind kind, int Cout, bool f16)
 {
     const int cpg = f16 ? 16 : 8;                // channels per k-group
-    if (kind == CONVT2X2) return ConvGeom{8, 128, 4 * cpg};
+    if (kind == CONVT2X2) return ConvGeom{8, 128, CONVT_KG * cpg};
     if (f16) return ConvGeom{32, 64, cpg};       // fp16 3x3: 32x16-pixel tiles x 64 couts for every layer
     if (Cout == 64) return ConvGeom{16, 64, cpg};
     return ConvGeom{8, 128, cpg};
