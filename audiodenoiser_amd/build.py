@@ -39,6 +39,7 @@ def _extra_flags():
         flags.append("-DADN_EXPERIMENTS")
         if os.environ.get("ADN_BUILD_STAMPS", "") not in ("", "0"):
             flags.append("-DADN_WINO_STAMPS")
+        flags += os.environ.get("ADN_BUILD_DEFINES", "").split()      # experiments only: extra -D switches of a sweep
     return flags
 
 

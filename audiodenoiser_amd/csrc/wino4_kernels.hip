@@ -21,8 +21,10 @@
 //   wave w: tile block (w >> 1) x position half (w & 1: columns 0-2 or 3-5 of the 6x6 transform domain) x 32 couts;
 //   lane (ti, q) transforms the patch of tile ti for channel pair q
 //   K walked in chunks of 8 input channels, two passes of 4 per chunk (pass h: lane q owns channel 2q + h): halo
-//   (34x34 px x 8 ch) and U (36 pos x 8 ch x 32 couts) are copied global -> LDS by LDS-DMA into one of two images
-//   while the other is consumed; one barrier per chunk.
+//   (34x34 px x 8 ch) and U (36 pos x 8 ch x 32 couts) are copied global -> LDS by LDS-DMA into two images.  The copies
+//   run ahead: U of chunk c+1 under the first pass of chunk c, halo of chunk c+2 under the second (a chunk's patch is read
+//   into registers one chunk ahead, under the second pass of the chunk before it, so the halo half of an image is free a
+//   whole chunk before its U half); two barriers per chunk, neither waits for a copy younger than a pass.
 #include "adn_internal.h"
 
 #include <atomic>
@@ -38,6 +40,12 @@ typedef const volatile f32x4 __attribute__((address_space(3))) lds4_cv_f32x4;
 namespace {
 
 constexpr int KC = 8;                        // input channels per chunk
+#ifndef W4_PR                                 // (tools/wino4_variants.sh sweeps these two: 5 from group 0 measured best, 35.17 ms per step;
+#define W4_PR 5                               //  4 / 6 / 10 per group 35.36 / 35.27 / 35.5, 5 from group 3 35.74)
+#define W4_PR0 0
+#endif
+constexpr int W4_PATCH_READS = W4_PR;        // patch reads of the next chunk behind each MFMA group of the second pass (30 in all),
+constexpr int W4_PATCH_FIRST = W4_PR0;       // from this group on
 constexpr int NT = 512;                      // threads per workgroup
 constexpr int REG = 32;                      // output pixels per workgroup edge
 constexpr int HP = REG + 2;                  // halo edge (rows; columns in the ordinary mode)
@@ -115,46 +123,49 @@ __device__ __forceinline__ void at6(float m0, float m1, float m2, float m3, floa
 // (in registers the loop needs, i.e. as scratch spills: measured 0.3 GB of spill traffic per full-resolution launch)
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
-// Which of the ten copy pieces of the next chunk goes out behind MFMA group gi (0..17: two passes of nine groups), -1 = none.
-// All placements are equivalent arithmetically; hipcc's schedule of the loop is not (38.6 ... 45.2 ms per batch-64 step over
-// the placements tried, profiles/r02_wino4_placement.txt), so the placement is chosen per epilogue variant by measurement
-// (tools/wino4_placement.sh).
-// W4_PLACE[placement][gi] = piece (0..9) or -1.  0: every other group; 1 / 6 / 2 / 14: two of every three starting at group
-// 0 / 1 / 2 / 3; 3: the first five groups of each pass; 5: all early; 7, 8: three of every four; the rest: irregular.
+// Copies run ahead of the arithmetic: under the FIRST pass of chunk c go the five U pieces of chunk c + 1, under the SECOND
+// pass the five halo pieces of chunk c + 2 (a chunk's patch is read one chunk ahead, below, so the halo half of an image is
+// free a whole chunk earlier than its U half).  W4_PLACE[placement][gi] = which piece (0..4 of the pass) goes out behind MFMA
+// group gi (0..17: two passes of nine groups), -1 = none.  All placements are equivalent arithmetically; hipcc's schedule of
+// the loop is not, so the placement is chosen per epilogue variant by measurement (tools/wino4_placement.sh).
 __device__ constexpr signed char W4_PLACE[16][18] = {
-    { 0, -1,  1, -1,  2, -1,  3, -1,  4, -1,  5, -1,  6, -1,  7, -1,  8,  9},
-    { 0,  1, -1,  2,  3, -1,  4,  5, -1,  6,  7, -1,  8,  9, -1, -1, -1, -1},
-    {-1, -1,  0,  1, -1,  2,  3, -1,  4,  5, -1,  6,  7, -1,  8,  9, -1, -1},
-    { 0,  1,  2,  3,  4, -1, -1, -1, -1,  5,  6,  7,  8,  9, -1, -1, -1, -1},
-    { 0, -1,  1, -1,  2, -1,  3, -1,  4,  5, -1,  6, -1,  7, -1,  8, -1,  9},
-    { 0,  1,  2,  3,  4,  5,  6,  7,  8,  9, -1, -1, -1, -1, -1, -1, -1, -1},
-    {-1,  0,  1, -1,  2,  3, -1,  4,  5, -1,  6,  7, -1,  8,  9, -1, -1, -1},
-    { 0,  1,  2, -1,  3,  4,  5, -1,  6,  7,  8, -1,  9, -1, -1, -1, -1, -1},
-    {-1,  0,  1,  2, -1,  3,  4,  5, -1,  6,  7,  8, -1,  9, -1, -1, -1, -1},
-    {-1,  0,  1, -1,  2,  3, -1,  4,  5, -1,  6,  7,  8,  9, -1, -1, -1, -1},
-    {-1,  0, -1,  1,  2, -1,  3,  4, -1,  5,  6, -1,  7,  8, -1,  9, -1, -1},
-    {-1,  0,  1, -1,  2,  3,  4, -1,  5, -1,  6,  7, -1,  8,  9, -1, -1, -1},
-    {-1, -1,  0,  1,  2, -1,  3,  4,  5, -1, -1,  6,  7,  8, -1,  9, -1, -1},
-    {-1,  0,  1, -1, -1,  2,  3,  4,  5, -1,  6,  7, -1, -1,  8,  9, -1, -1},
-    {-1, -1, -1,  0,  1, -1,  2,  3, -1,  4,  5, -1,  6,  7, -1,  8,  9, -1},
-    {-1,  0,  1,  2,  3,  4, -1, -1, -1, -1,  5,  6,  7,  8,  9, -1, -1, -1},
+    { 0, -1,  1, -1,  2, -1,  3, -1,  4,   0, -1,  1, -1,  2, -1,  3, -1,  4},    //  0 every other group
+    { 0,  1,  2,  3,  4, -1, -1, -1, -1,   0,  1,  2,  3,  4, -1, -1, -1, -1},    //  1 the first five groups
+    {-1,  0,  1,  2,  3,  4, -1, -1, -1,  -1,  0,  1,  2,  3,  4, -1, -1, -1},    //  2 five from group 1
+    {-1, -1,  0,  1,  2,  3,  4, -1, -1,  -1, -1,  0,  1,  2,  3,  4, -1, -1},    //  3 five from group 2
+    {-1, -1, -1, -1,  0,  1,  2,  3,  4,  -1, -1, -1, -1,  0,  1,  2,  3,  4},    //  4 the last five groups
+    { 0,  1, -1,  2,  3, -1,  4, -1, -1,   0,  1, -1,  2,  3, -1,  4, -1, -1},    //  5 two of every three from group 0
+    {-1,  0,  1, -1,  2,  3, -1,  4, -1,  -1,  0,  1, -1,  2,  3, -1,  4, -1},    //  6 two of every three from group 1
+    { 0,  1,  2,  3,  4, -1, -1, -1, -1,   0, -1,  1, -1,  2, -1,  3, -1,  4},    //  7 U early, halo every other group
+    { 0, -1,  1, -1,  2, -1,  3, -1,  4,   0,  1,  2,  3,  4, -1, -1, -1, -1},    //  8 U every other group, halo early
+    { 0,  1,  2,  3,  4, -1, -1, -1, -1,  -1, -1, -1, -1,  0,  1,  2,  3,  4},    //  9 U early, halo late
+    {-1, -1, -1, -1,  0,  1,  2,  3,  4,   0,  1,  2,  3,  4, -1, -1, -1, -1},    // 10 U late, halo early
+    {-1,  0, -1,  1, -1,  2, -1,  3,  4,  -1,  0, -1,  1, -1,  2, -1,  3,  4},    // 11 every other group from group 1
+    { 0,  1,  2, -1, -1,  3,  4, -1, -1,   0,  1,  2, -1, -1,  3,  4, -1, -1},    // 12 3 + 2
+    {-1,  0,  1,  2,  3,  4, -1, -1, -1,   0, -1,  1, -1,  2, -1,  3, -1,  4},    // 13
+    {-1,  0,  1, -1,  2,  3, -1,  4, -1,   0,  1,  2,  3,  4, -1, -1, -1, -1},    // 14
+    { 0, -1, -1,  1, -1,  2, -1,  3,  4,   0, -1, -1,  1, -1,  2, -1,  3,  4},    // 15
 };
 __host__ __device__ constexpr int w4_piece_at(int PL, int gi) { return W4_PLACE[PL & 15][gi]; }
-constexpr bool w4_placements_valid()                    // every row places each of the ten pieces exactly once
+constexpr bool w4_placements_valid()                    // every row places each of the five pieces of each pass exactly once
 {
-    for (int pl = 0; pl < 16; ++pl) {
-        int seen = 0;
-        for (int gi = 0; gi < 18; ++gi)
-            if (W4_PLACE[pl][gi] >= 0) {
-                if (W4_PLACE[pl][gi] > 9 || (seen >> W4_PLACE[pl][gi]) & 1) return false;
-                seen |= 1 << W4_PLACE[pl][gi];
+    for (int pl = 0; pl < 16; ++pl)
+        for (int h = 0; h < 2; ++h) {
+            int seen = 0;
+            for (int g = 0; g < 9; ++g) {
+                const int k = W4_PLACE[pl][9 * h + g];
+                if (k >= 0) {
+                    if (k > 4 || (seen >> k) & 1) return false;
+                    seen |= 1 << k;
+                }
             }
-        if (seen != 0x3ff) return false;
-    }
+            if (seen != 0x1f) return false;
+        }
     return true;
 }
-static_assert(w4_placements_valid(), "W4_PLACE: each placement must issue pieces 0..9 exactly once");
-constexpr int w4_default_placement(int EPI) { return EPI == CONV3X3_RELU_DOT ? 0 : 6; }
+static_assert(w4_placements_valid(), "W4_PLACE: each placement must issue pieces 0..4 exactly once per pass");
+constexpr int w4_default_placement(int) { return 4; }     // late copies measured best for all three epilogue variants
+static_assert(W4_PR * (9 - W4_PR0) >= 30, "the second pass must issue all 30 patch reads");
 
 // ABL: timing experiments (-DADN_EXPERIMENTS builds, ADN_WINO4_ABLATE): 1 no copies after the first chunk, 2 no patch
 // reads / transform, 4 no transform, 8 no barrier, 16 no B-fragment reads, 32 no U copies, 64 no halo copies, 128 every
@@ -208,6 +219,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
     for (int k = 0; k < UR; ++k)
         if (k * NT + wave * 64 < USLOTS) dma16(urs, uoff, usoff + k * NT * 16, smem + (HSLOTS + k * NT + wave * 64) * 4);
+    usoff += USLOTS * 16;
 
     // DMA plan of the halo: slot s = r*NT + tid -> (row, pixel, channel half); byte offsets into the current source, OOB = zeros
     unsigned hcur[HR];                                  // byte offsets inside the source image(s), OOB = padding
@@ -243,31 +255,31 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     unsigned hsoff = 0;                                 // byte offset of the next chunk's channel block
     unsigned cstr = (unsigned)(p.s0.H * p.s0.W) * 32u;  // bytes between consecutive channel blocks of the current source
 
-#define W4_DMA_BEGIN(c)                                                                        \
+    // halo of chunk ch (absolute index): switch of the source at the virtual concat, HR wave-instructions, advance
+#define W4_HALO_BEGIN(ch)                                                                      \
     do {                                                                                       \
-        if ((c) == p.nchunk0) {                       /* wave-uniform: switch to the second source (virtual concat) */ \
+        if ((ch) == p.nchunk0) {                      /* wave-uniform: switch to the second source (virtual concat) */ \
             hrs = src_rsrc(p.s1);                                                              \
             hsoff = 0;                                                                         \
             cstr = (unsigned)(p.s1.H * p.s1.W) * 32u;                                          \
             plan(p.s1);                                                                        \
         }                                                                                      \
     } while (0)
-    // piece k of the HR + UR wave-instructions that copy a chunk into image buf
-#define W4_DMA_PIECE(k, buf)                                                                   \
+#define W4_HALO_PIECE(k, buf)                                                                  \
     do {                                                                                       \
         float *dst_ = smem + (buf) * IMG + ((k) * NT + wave * 64) * 4;                         \
-        if ((k) < HR) {                                                                        \
-            if (ABL & 256) dma16(hrs, (((k) * NT + tid) * 16) % 32768, hsoff, dst_);   /* contiguous stand-in for the halo gather */ \
-            else if (!(ABL & 64)) dma16(hrs, (ABL & 128) ? OOB : hcur[(k) < HR ? (k) : 0], hsoff, dst_); \
-        } else if (((k) - HR) * NT + wave * 64 < USLOTS && !(ABL & 32))                        \
-            dma16(urs, (ABL & 128) ? OOB : uoff, usoff + ((k) - HR) * NT * 16, dst_);          \
+        if (ABL & 256) dma16(hrs, (((k) * NT + tid) * 16) % 32768, hsoff, dst_);   /* contiguous stand-in for the halo gather */ \
+        else if (!(ABL & 64)) dma16(hrs, (ABL & 128) ? OOB : hcur[(k) < HR ? (k) : 0], hsoff, dst_); \
     } while (0)
-#define W4_DMA_END()                                                                           \
+#define W4_HALO_END() hsoff += cstr
+    // U slab of the next chunk: UR wave-instructions (the last round exists in waves 0-3 only)
+#define W4_U_PIECE(k, buf)                                                                     \
     do {                                                                                       \
-        hsoff += cstr;                                                                         \
-        usoff += USLOTS * 16;                                                                  \
+        if ((k) * NT + wave * 64 < USLOTS && !(ABL & 32))                                      \
+            dma16(urs, (ABL & 128) ? OOB : uoff, usoff + (k) * NT * 16, smem + (buf) * IMG + (HSLOTS + (k) * NT + wave * 64) * 4); \
     } while (0)
-
+#define W4_U_END() usoff += USLOTS * 16
+    static_assert(HR == 5 && UR == 5, "W4_PLACE and the vmcnt immediates below assume five pieces per pass");
 
     // after the epilogue's exchange this wave finishes cout block jh of its tile block
     const float bias_pre = LEAN ? 0.f : p.bias[ct * 32 + 16 * jh + ti];
@@ -286,12 +298,32 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int a_hi = a_lo + 4;                              // rows 4-5: the next group of four halo rows
     const int b_lane = (jh * 9 * 2 * 64 + lane) * 4;        // U slab [jh][group of 2 positions][pass][q][cout%16][pos%2][cout block]
 
-    W4_DMA_BEGIN(0);
+    W4_HALO_BEGIN(0);
 #pragma unroll
-    for (int k = 0; k < HR; ++k) W4_DMA_PIECE(k, 0);
-    W4_DMA_END();
+    for (int k = 0; k < HR; ++k) W4_HALO_PIECE(k, 0);
+    W4_HALO_END();
     if (!(ABL & 8192)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // 8192: timing experiment, first chunk not awaited
     __syncthreads();
+    // the halo of chunk 1 goes out at once (image 1 has no reader yet); from here on the halo runs two chunks ahead
+    if (p.nchunk > 1 && !(ABL & 1)) {
+        W4_HALO_BEGIN(1);
+#pragma unroll
+        for (int k = 0; k < HR; ++k) W4_HALO_PIECE(k, 1);
+        W4_HALO_END();
+    }
+    // Waits of the K loop.  Barrier between the passes of chunk c: the halo of chunk c + 1 (issued a pass or more ago) has
+    // landed, the U pieces of this pass (five in waves 0-3, four in waves 4-7) may still be in flight.  Barrier at the end of
+    // chunk c: the U slab of chunk c + 1 has landed, the five halo pieces of chunk c + 2 issued behind it may be in flight.
+#define W4_WAIT_MID()                                                                          \
+    do {                                                                                       \
+        if (wave >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                        \
+        else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");                                  \
+    } while (0)
+#define W4_WAIT_END(more2)                                                                     \
+    do {                                                                                       \
+        if (more2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");                            \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                  \
+    } while (0)
 
     // Tile blocks that lie wholly outside the image (rows 528-543 of a 513-row input; the partner clip of an odd last clip in
     // pair mode) do no arithmetic: their two waves keep copying their share of every chunk and meet every barrier, so the
@@ -316,17 +348,25 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
     };
     if (LEAN && !active) {                              // (the plain variant's register allocation suffers from this branch: -3 %)
-        for (int c = 0; c + 1 < p.nchunk; ++c) {
-            W4_DMA_BEGIN(c + 1);
+        for (int c = 0; c < p.nchunk; ++c) {
+            const bool more1 = c + 1 < p.nchunk && !((ABL & 1) && c >= 1), more2 = c + 2 < p.nchunk && !(ABL & 1);
+            if (more1) {
 #pragma unroll
-            for (int k = 0; k < HR + UR; ++k) W4_DMA_PIECE(k, (c + 1) & 1);
-            W4_DMA_END();
-            if (!(ABL & 8)) __builtin_amdgcn_s_barrier();   // the barrier between the passes
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (!(ABL & 8)) __syncthreads();
+                for (int k = 0; k < UR; ++k) W4_U_PIECE(k, (c + 1) & 1);
+                W4_U_END();
+            }
+            W4_WAIT_MID();
+            if (!(ABL & 8)) __builtin_amdgcn_s_barrier();
+            if (more2) {
+                W4_HALO_BEGIN(c + 2);
+#pragma unroll
+                for (int k = 0; k < HR; ++k) W4_HALO_PIECE(k, c & 1);
+                W4_HALO_END();
+            }
+            W4_WAIT_END(more2);
+            if (!(ABL & 8)) __builtin_amdgcn_s_barrier();
         }
-        if (!(ABL & 8)) __builtin_amdgcn_s_barrier();   // the last chunk's two barriers
-        if (!(ABL & 8)) __syncthreads();
+        __syncthreads();                                // the images are free for the epilogue
         if constexpr (ABL & 2048) return;
         __syncthreads();                                // epilogue: exchange blocks written
         if constexpr (EPI == CONV3X3_RELU_DOT) {
@@ -338,27 +378,36 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
 
     constexpr int abl = ABL;
-    for (int c = 0; c < p.nchunk; ++c) {
-        const bool more = c + 1 < p.nchunk && !((abl & 1) && c >= 1);
-        const int nb = (c + 1) & 1;
-        if (more) W4_DMA_BEGIN(c + 1);
-        const float *sA = smem + (c & 1) * IMG;
-        const float *sB = sA + HSLOTS * 4;
-        // one read serves both passes: .x = channel 2q (pass 0), .y = channel 2q + 1 (pass 1).  (Running the row stage of both
-        // passes as the rows land -- 36 live values instead of 60, 217 VGPRs and no spill -- measured 2.7 % slower: written this
-        // way hipcc sinks each transform operation to just in front of the MFMA group that needs it.)
-        f32x2 d[6][5];
-        if (!(abl & 2)) {
+    // The patch of a chunk: one read serves both passes, .x = channel 2q (pass 0), .y = channel 2q + 1 (pass 1).  It is read
+    // one chunk AHEAD: the halo of chunk c + 1 is complete at the barrier between the passes of chunk c (its pieces went out
+    // under the second pass of chunk c - 1); the second pass's row stage has consumed d, so its MFMA groups are followed by
+    // the 30 reads of chunk c + 1's patch (W4_PATCH_READS at a time) and no wave reads patches behind the chunk barrier,
+    // where all eight waves' reads (120 KB, ~1000 cycles of LDS time) used to stand between the barrier and the first MFMA.
+    // That frees the halo half of image c & 1 from the barrier between the passes on: the halo of chunk c + 2 is copied
+    // into it under the second pass, the U slab of chunk c + 1 under the first, and no barrier waits for a copy issued
+    // less than a pass before it.
+    f32x2 d[6][5];
+    auto read_patch = [&](int img, int i0, int i1) {
+        const float *sI = smem + img * IMG;
 #pragma unroll
-            for (int ao = 0; ao < 6; ++ao) {
-                // rows 0, 2, 4 first: the first MFMA group's positions (transform-domain row 0) need only those
-                const int a = ao < 3 ? 2 * ao : 2 * ao - 5;
-#pragma unroll
-                for (int k = 0; k < 5; ++k) d[a][k] = *(lds4_cv_f32x2 *)(sA + (a < 4 ? a_lo : a_hi) + (a * RSL + k) * 4);
+        for (int i = i0; i < i1; ++i) {
+            if (i < 30) {
+                const int ao = i / 5, k = i % 5;
+                const int a = ao < 3 ? 2 * ao : 2 * ao - 5;      // rows 0, 2, 4 first (the first MFMA groups need only those)
+                d[a][k] = *(lds4_cv_f32x2 *)(sI + (a < 4 ? a_lo : a_hi) + (a * RSL + k) * 4);
             }
         }
+    };
+    if (!(abl & 2)) read_patch(0, 0, 30);
+#pragma clang loop unroll(disable)                      // (also keeps hipcc from peeling the last iteration, whose copy spilled 60 registers)
+    for (int c = 0; c < p.nchunk; ++c) {
+        const bool more = c + 1 < p.nchunk && !((abl & 1) && c >= 1), more2 = c + 2 < p.nchunk && !(abl & 1);
+        const int nb = (c + 1) & 1;
+        const float *sA = smem + (c & 1) * IMG;
+        const float *sB = sA + HSLOTS * 4;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
+            if (h == 1 && more2) W4_HALO_BEGIN(c + 2);
             float V[18];                                // [row i of the transform domain][own column]
             if (abl & 2) {
 #pragma unroll
@@ -407,27 +456,42 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 W4_LANDED(u[g & 1]);
                 if (g < 8 && !(abl & 16)) W4_LOADU(u[(g + 1) & 1], g + 1);
                 __builtin_amdgcn_sched_barrier(0);
-                if (more && w4_piece_at(PL, 9 * h + g) >= 0) W4_DMA_PIECE((w4_piece_at(PL, 9 * h + g) >= 0 ? w4_piece_at(PL, 9 * h + g) : 0), nb);
+                if (w4_piece_at(PL, 9 * h + g) >= 0) {
+                    const int pk = w4_piece_at(PL, 9 * h + g) >= 0 ? w4_piece_at(PL, 9 * h + g) : 0;
+                    if (h == 0 && more) W4_U_PIECE(pk, nb);
+                    if (h == 1 && more2) W4_HALO_PIECE(pk, c & 1);
+                }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
                     acc[s & 1][2 * g + (s >> 1)] =
                         __builtin_amdgcn_mfma_f32_16x16x4f32(V[2 * g + (s >> 1)], u[g & 1][s], acc[s & 1][2 * g + (s >> 1)], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
+                if (h == 1 && !(abl & 2)) {                 // unconditional (the last chunk reads a stale image): no branch, exact waitcnts
+                    if (g >= W4_PATCH_FIRST) read_patch(nb, W4_PATCH_READS * (g - W4_PATCH_FIRST), W4_PATCH_READS * (g - W4_PATCH_FIRST + 1));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
 #undef W4_LOADU
 #undef W4_LANDED
-            // a second, data-free barrier between the passes keeps the eight waves in step (measured: 36.0 -> 35.6 ms per step)
-            if (h == 0 && !(abl & 8)) __builtin_amdgcn_s_barrier();
+            if (h == 0) {                               // barrier between the passes
+                if (more) W4_U_END();
+                W4_WAIT_MID();
+                if (!(abl & 8)) __builtin_amdgcn_s_barrier();
+            }
         }
-        if (more) W4_DMA_END();
-        // every wave: its own DMA writes have landed (vmcnt); then all waves: image c is free, image c+1 complete
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (!(abl & 8)) __syncthreads();
+        if (more2) W4_HALO_END();
+        W4_WAIT_END(more2);                             // image c's U half is free behind this barrier, image c + 1 complete
+        if (!(abl & 8)) __builtin_amdgcn_s_barrier();
     }
-#undef W4_DMA_BEGIN
-#undef W4_DMA_PIECE
-#undef W4_DMA_END
+#undef W4_HALO_BEGIN
+#undef W4_HALO_PIECE
+#undef W4_HALO_END
+#undef W4_U_PIECE
+#undef W4_U_END
+#undef W4_WAIT_MID
+#undef W4_WAIT_END
+    __syncthreads();                                    // LDS reads of every wave have landed: the images are free for the epilogue
 
     if constexpr (ABL & 2048) {                         // timing experiment: no epilogue (one store keeps the accumulators alive)
         float keep = 0.f;
