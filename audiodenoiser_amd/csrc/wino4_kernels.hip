@@ -40,6 +40,9 @@ typedef const volatile f32x4 __attribute__((address_space(3))) lds4_cv_f32x4;
 namespace {
 
 constexpr int KC = 8;                        // input channels per chunk
+#ifndef W4_TPIN                               // 1: the whole input transform of a pass in front of its first MFMA (below)
+#define W4_TPIN 1
+#endif
 #ifndef W4_PR                                 // (tools/wino4_variants.sh sweeps these two: 5 from group 0 measured best, 35.17 ms per step;
 #define W4_PR 5                               //  4 / 6 / 10 per group 35.36 / 35.27 / 35.5, 5 from group 3 35.74)
 #define W4_PR0 0
@@ -441,6 +444,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 // column stage
 #pragma unroll
                 for (int b = 0; b < 3; ++b) bt6(V[0 * 3 + b], V[1 * 3 + b], V[2 * 3 + b], V[3 * 3 + b], V[4 * 3 + b], V[5 * 3 + b]);
+#if W4_TPIN
+                // The whole transform stays in front of the pass's first MFMA (hipcc would sink each operation to the group that
+                // needs it): VALU operations woven into the MFMA stream cost more than the same operations in one block behind the
+                // barrier -- measured 34.8 (pinned) / 35.0 (sunk by the compiler) / 36.6 (whole transform of the next pass in front
+                // of the barrier) / 37.6-38.3 ms per step (row stage of the next pass under the late MFMA groups of this one).
+#pragma unroll
+                for (int i = 0; i < 18; ++i) asm volatile("" : "+v"(V[i]));
+#endif
             }
             // B fragments: one ds_read_b128 per group of two positions x two cout blocks, read one group ahead of its
             // MFMAs (the empty asm consumes the landed fragment, so the next read is issued behind that wait and flies
