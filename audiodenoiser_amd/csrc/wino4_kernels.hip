@@ -27,8 +27,12 @@
 //   whole chunk before its U half); two barriers per chunk, neither waits for a copy younger than a pass.
 #include "adn_internal.h"
 
+#include <algorithm>
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
+#include <type_traits>
+#include <vector>
 
 namespace adn {
 
@@ -184,6 +188,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // form, which spills 7 registers once per workgroup.
     constexpr bool LEAN = EPI != CONV3X3_RELU;
 
+#ifdef ADN_EXPERIMENTS
+    // workgroup timeline (ADN_W4_TIMELINE, p.dbg != nullptr): clock at entry / first chunk ready / loop done / stores issued /
+    // stores drained + the hardware id of the CU, written by wave 0; launch_wino4_conv prints the per-CU averages
+    const unsigned long long tl0 = __builtin_amdgcn_s_memtime();
+    unsigned long long tl1 = 0, tl2 = 0;
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -307,6 +317,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     W4_HALO_END();
     if (!(ABL & 8192)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // 8192: timing experiment, first chunk not awaited
     __syncthreads();
+#ifdef ADN_EXPERIMENTS
+    tl1 = __builtin_amdgcn_s_memtime();
+#endif
     // the halo of chunk 1 goes out at once (image 1 has no reader yet); from here on the halo runs two chunks ahead
     if (p.nchunk > 1 && !(ABL & 1)) {
         W4_HALO_BEGIN(1);
@@ -503,6 +516,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #undef W4_WAIT_MID
 #undef W4_WAIT_END
     __syncthreads();                                    // LDS reads of every wave have landed: the images are free for the epilogue
+#ifdef ADN_EXPERIMENTS
+    tl2 = __builtin_amdgcn_s_memtime();
+#endif
 
     if constexpr (ABL & 2048) {                         // timing experiment: no epilogue (one store keeps the accumulators alive)
         float keep = 0.f;
@@ -588,31 +604,72 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     float *pb = (EPI == CONV3X3_RELU_POOL)
                     ? static_cast<float *>(p.pool) + (size_t)nb * Hp * Wp * p.Cout + act_off<float>(p.Cout, (long)Hp * Wp, 0, col)
                     : nullptr;
+    const int gy0e = ty * REG + 16 * by + 4 * eq, gx0e = tx * REG + (pair ? 0 : 16 * bx);
+#ifndef W4_EPI_FAST
+#define W4_EPI_FAST 1
+#endif
+    const bool interior = W4_EPI_FAST && clip_ok && ty * REG + 16 * by + 16 <= p.H && gx0e + 16 <= p.W;       // wave-uniform
+    auto finish = [&](auto interior_tag) {
+        constexpr bool INT = decltype(interior_tag)::value;
+        float *orow[4], *prow[2];
+        if constexpr (INT) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        float y[4][4];
-        partial(acc[0], r, y);
-        const int gy = ty * REG + 16 * by + 4 * eq, gx = tx * REG + (pair ? 0 : 16 * bx) + 4 * r;
+            for (int a = 0; a < 4; ++a) orow[a] = ob + ((size_t)(gy0e + a) * p.W + gx0e) * 8;
+            if (EPI == CONV3X3_RELU_POOL) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const f32x4 o = *reinterpret_cast<const f32x4 *>(xr + (r * 4 + a) * 256);
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                y[a][b] = fmaxf(y[a][b] + o[b] + bias_r, 0.f);
-                if (clip_ok && gy + a < p.H && gx + b < p.W && (!(ABL & 4096) || y[a][b] == 123.456f)) ob[((size_t)(gy + a) * p.W + gx + b) * 8] = y[a][b];
+                for (int a = 0; a < 2; ++a) prow[a] = pb + ((size_t)((gy0e >> 1) + a) * Wp + (gx0e >> 1)) * 8;
             }
         }
-        if (EPI == CONV3X3_RELU_POOL) {
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+        for (int r = 0; r < 4; ++r) {
+            float y[4][4];
+            partial(acc[0], r, y);
+            const int gy = gy0e, gx = gx0e + 4 * r;
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const float mx = fmaxf(fmaxf(y[2 * a][2 * b], y[2 * a][2 * b + 1]), fmaxf(y[2 * a + 1][2 * b], y[2 * a + 1][2 * b + 1]));
-                    const int py = (gy >> 1) + a, px = (gx >> 1) + b;
-                    if (clip_ok && py < Hp && px < Wp && (!(ABL & 4096) || mx == 123.456f)) pb[((size_t)py * Wp + px) * 8] = mx;
+            for (int a = 0; a < 4; ++a) {
+                const f32x4 o = *reinterpret_cast<const f32x4 *>(xr + (r * 4 + a) * 256);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    y[a][b] = fmaxf(y[a][b] + o[b] + bias_r, 0.f);
+                    if constexpr (INT) {
+                        if (!(ABL & 4096) || y[a][b] == 123.456f) orow[a][(4 * r + b) * 8] = y[a][b];
+                    } else {
+                        if (clip_ok && gy + a < p.H && gx + b < p.W && (!(ABL & 4096) || y[a][b] == 123.456f))
+                            ob[((size_t)(gy + a) * p.W + gx + b) * 8] = y[a][b];
+                    }
                 }
+            }
+            if (EPI == CONV3X3_RELU_POOL) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const float mx = fmaxf(fmaxf(y[2 * a][2 * b], y[2 * a][2 * b + 1]), fmaxf(y[2 * a + 1][2 * b], y[2 * a + 1][2 * b + 1]));
+                        if constexpr (INT) {
+                            if (!(ABL & 4096) || mx == 123.456f) prow[a][(2 * r + b) * 8] = mx;
+                        } else {
+                            const int py = (gy >> 1) + a, px = (gx >> 1) + b;
+                            if (clip_ok && py < Hp && px < Wp && (!(ABL & 4096) || mx == 123.456f)) pb[((size_t)py * Wp + px) * 8] = mx;
+                        }
+                    }
+            }
+        }
+    };
+    if (interior) finish(std::true_type{});
+    else finish(std::false_type{});
+#ifdef ADN_EXPERIMENTS
+    if (p.dbg && wave == 0) {
+        const unsigned long long tl3 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long tl4 = __builtin_amdgcn_s_memtime();
+        const unsigned hwid = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));        // HW_REG_HW_ID
+        const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));        // HW_REG_XCC_ID
+        if (lane == 0) {
+            unsigned long long *o = reinterpret_cast<unsigned long long *>(p.dbg) + (size_t)blockIdx.x * 8;
+            o[0] = tl0; o[1] = tl1; o[2] = tl2; o[3] = tl3; o[4] = tl4; o[5] = ((unsigned long long)xcc << 32) | hwid;
         }
     }
+#endif
 }
 
 }  // namespace
@@ -696,6 +753,51 @@ hipError_t launch_wino4_conv(ConvKind kind, const ConvArgs &a, hipStream_t st)
         if (e != hipSuccess) return e;
         void *args[] = {&a2};
         return hipLaunchKernel(f, dim3((unsigned)nwg), dim3(NT), args, LDS_BYTES, st);
+    }
+#endif
+#ifdef ADN_EXPERIMENTS
+    static const bool timeline = std::getenv("ADN_W4_TIMELINE") != nullptr;
+    if (timeline && kind != CONV3X3_RELU_DOT) {
+        const size_t bytes = (size_t)nwg * 8 * sizeof(unsigned long long);
+        if (hipMalloc(&a2.dbg, bytes) != hipSuccess) return hipErrorOutOfMemory;
+        (void)hipMemset(a2.dbg, 0, bytes);
+        if (kind == CONV3X3_RELU_POOL)
+            hipLaunchKernelGGL(wino4_conv_f32<CONV3X3_RELU_POOL>, dim3((unsigned)nwg), dim3(NT), LDS_BYTES, st, a2);
+        else
+            hipLaunchKernelGGL(wino4_conv_f32<CONV3X3_RELU>, dim3((unsigned)nwg), dim3(NT), LDS_BYTES, st, a2);
+        (void)hipStreamSynchronize(st);
+        std::vector<unsigned long long> hb(bytes / 8);
+        (void)hipMemcpy(hb.data(), a2.dbg, bytes, hipMemcpyDeviceToHost);
+        (void)hipFree(a2.dbg);
+        struct Rec { unsigned long long key, t0, t1, t2, t3, t4; };
+        std::vector<Rec> recs;
+        for (long b = 0; b < nwg; ++b)
+            if (hb[b * 8 + 4]) {
+                const unsigned hw = (unsigned)hb[b * 8 + 5], xcc = (unsigned)(hb[b * 8 + 5] >> 32);
+                const unsigned long long key = ((unsigned long long)(xcc & 15) << 16) | ((hw >> 8) & 0xff);   // xcc, (se, sh, cu)
+                recs.push_back({key, hb[b * 8], hb[b * 8 + 1], hb[b * 8 + 2], hb[b * 8 + 3], hb[b * 8 + 4]});
+            }
+        std::sort(recs.begin(), recs.end(), [](const Rec &x, const Rec &y) { return x.key != y.key ? x.key < y.key : x.t0 < y.t0; });
+        double pro = 0, loop = 0, epi = 0, drain = 0, gap = 0, span = 0;
+        long ngap = 0, ncu = 0;
+        unsigned long long first = ~0ull, last = 0;
+        for (size_t i = 0; i < recs.size(); ++i) {
+            pro += (double)(recs[i].t1 - recs[i].t0);
+            loop += (double)(recs[i].t2 - recs[i].t1);
+            epi += (double)(recs[i].t3 - recs[i].t2);
+            drain += (double)(recs[i].t4 - recs[i].t3);
+            if (i + 1 < recs.size() && recs[i + 1].key == recs[i].key) { gap += (double)((long long)(recs[i + 1].t0 - recs[i].t4)); ++ngap; }
+            if (i == 0 || recs[i].key != recs[i - 1].key) ++ncu;
+            if (recs[i].t0 < first) first = recs[i].t0;
+            if (recs[i].t4 > last) last = recs[i].t4;
+        }
+        span = (double)(last - first);
+        const double nr = recs.empty() ? 1.0 : (double)recs.size();
+        std::fprintf(stderr, "[w4 timeline] H %d W %d nchunk %d Cout %d: %zu workgroups on %ld CUs, clocks per workgroup: prologue %.0f  "
+                             "K loop %.0f (%.0f per chunk)  epilogue %.0f  store drain %.0f  gap to the next workgroup on the CU %.0f;  "
+                             "launch span %.0f clocks\n", a2.H, a2.W, a2.nchunk, a2.Cout, recs.size(), ncu, pro / nr, loop / nr,
+                     loop / nr / a2.nchunk, epi / nr, drain / nr, ngap ? gap / ngap : 0.0, span);
+        return hipGetLastError();
     }
 #endif
     static_assert(8 * (256 * 17 + 32) * sizeof(float) <= LDS_BYTES, "staging of the fused 1x1 epilogue must fit the images");
