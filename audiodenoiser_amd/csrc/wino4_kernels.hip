@@ -192,7 +192,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // workgroup timeline (ADN_W4_TIMELINE, p.dbg != nullptr): clock at entry / first chunk ready / loop done / stores issued /
     // stores drained + the hardware id of the CU, written by wave 0; launch_wino4_conv prints the per-CU averages
     const unsigned long long tl0 = __builtin_amdgcn_s_memtime();
-    unsigned long long tl1 = 0, tl2 = 0;
+    unsigned long long tl1 = 0, tl2 = 0, tla = 0, tlb = 0, tlc = 0;
 #endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -223,6 +223,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int n = (pt / p.tilesY) << pair;               // (first) clip of the tile
     const int gy0 = ty * REG - 1, gx0 = tx * REG - 1;
 
+#ifdef ADN_EXPERIMENTS
+    asm volatile("" ::"s"(n), "s"(ty), "s"(tx), "s"(ct));
+    tla = __builtin_amdgcn_s_memtime();                 // tile decoded
+#endif
     // U slab of the first chunk: needs no plan, flies under the index arithmetic below
     const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(static_cast<const float *>(p.wpk)) + (size_t)ct * p.nchunk * (USLOTS * 4), 0,
@@ -315,7 +319,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
     for (int k = 0; k < HR; ++k) W4_HALO_PIECE(k, 0);
     W4_HALO_END();
+#ifdef ADN_EXPERIMENTS
+    tlb = __builtin_amdgcn_s_memtime();                 // first copies issued
+#endif
     if (!(ABL & 8192)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // 8192: timing experiment, first chunk not awaited
+#ifdef ADN_EXPERIMENTS
+    tlc = __builtin_amdgcn_s_memtime();                 // this wave's copies landed
+#endif
     __syncthreads();
 #ifdef ADN_EXPERIMENTS
     tl1 = __builtin_amdgcn_s_memtime();
@@ -667,6 +677,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         if (lane == 0) {
             unsigned long long *o = reinterpret_cast<unsigned long long *>(p.dbg) + (size_t)blockIdx.x * 8;
             o[0] = tl0; o[1] = tl1; o[2] = tl2; o[3] = tl3; o[4] = tl4; o[5] = ((unsigned long long)xcc << 32) | hwid;
+            o[6] = ((tla - tl0) << 32) | ((tlb - tla) & 0xffffffffull); o[7] = tlc - tlb;
         }
     }
 #endif
@@ -778,7 +789,9 @@ hipError_t launch_wino4_conv(ConvKind kind, const ConvArgs &a, hipStream_t st)
                 recs.push_back({key, hb[b * 8], hb[b * 8 + 1], hb[b * 8 + 2], hb[b * 8 + 3], hb[b * 8 + 4]});
             }
         std::sort(recs.begin(), recs.end(), [](const Rec &x, const Rec &y) { return x.key != y.key ? x.key < y.key : x.t0 < y.t0; });
-        double pro = 0, loop = 0, epi = 0, drain = 0, gap = 0, span = 0;
+        double pro = 0, loop = 0, epi = 0, drain = 0, gap = 0, span = 0, dec = 0, iss = 0, land = 0;
+        for (long b = 0; b < nwg; ++b)
+            if (hb[b * 8 + 4]) { dec += (double)(hb[b * 8 + 6] >> 32); iss += (double)(hb[b * 8 + 6] & 0xffffffffull); land += (double)hb[b * 8 + 7]; }
         long ngap = 0, ncu = 0;
         unsigned long long first = ~0ull, last = 0;
         for (size_t i = 0; i < recs.size(); ++i) {
@@ -795,8 +808,8 @@ hipError_t launch_wino4_conv(ConvKind kind, const ConvArgs &a, hipStream_t st)
         const double nr = recs.empty() ? 1.0 : (double)recs.size();
         std::fprintf(stderr, "[w4 timeline] H %d W %d nchunk %d Cout %d: %zu workgroups on %ld CUs, clocks per workgroup: prologue %.0f  "
                              "K loop %.0f (%.0f per chunk)  epilogue %.0f  store drain %.0f  gap to the next workgroup on the CU %.0f;  "
-                             "launch span %.0f clocks\n", a2.H, a2.W, a2.nchunk, a2.Cout, recs.size(), ncu, pro / nr, loop / nr,
-                     loop / nr / a2.nchunk, epi / nr, drain / nr, ngap ? gap / ngap : 0.0, span);
+                             "launch span %.0f clocks; prologue = decode %.0f + copies issued %.0f + landed %.0f + barrier\n", a2.H, a2.W, a2.nchunk, a2.Cout, recs.size(), ncu, pro / nr, loop / nr,
+                     loop / nr / a2.nchunk, epi / nr, drain / nr, ngap ? gap / ngap : 0.0, span, dec / nr, iss / nr, land / nr);
         return hipGetLastError();
     }
 #endif
