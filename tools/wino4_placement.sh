@@ -1,5 +1,5 @@
 #!/bin/bash
-# Copy-piece placement sweep of the F(4x4,3x3) kernel (experiments build: ADN_BUILD_EXPERIMENTS=1 python -m audiodenoiser_amd.build).
+# Copy-piece placement sweep of the F(4x4,3x3) kernel (W4_PLACE: which MFMA groups of a pass are followed by one of its five copy pieces) (experiments build: ADN_BUILD_EXPERIMENTS=1 python -m audiodenoiser_amd.build).
 # Usage (GPU box): bash tools/wino4_placement.sh [placements...]  -> gpurun_out/wino4_placement.txt
 # Every placement is arithmetically identical; the table shows, per epilogue variant, the summed time of its launches.
 export ADN_BUILD_EXPERIMENTS=1
