@@ -8,6 +8,7 @@ tail -1 gpurun_out/r02b_pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')"
 bash tools/profile_bench.sh r02b > gpurun_out/r02b_profile.log 2>&1 || { tail -20 gpurun_out/r02b_profile.log; exit 1; }
 tail -3 gpurun_out/r02b_profile.log
+cp gpurun_out/prof_r02b/summary/pmc_traffic.json profiles/pmc_traffic.json     # the bench line below reads the traffic of THIS build
 python bench.py > gpurun_out/r02b_bench.json 2> gpurun_out/r02b_bench.err
 python bench.py --batch-per-gpu 256 --steps 30 --no-extras --no-cpu-baseline > gpurun_out/r02b_bench_b256.json 2>/dev/null
 (python tools/report_parity.py; ADN_WINO_TILE=2 python tools/report_parity.py | sed 's/^winograd /wino F(2,3)/'; ADN_CONV_ALGO=direct python tools/report_parity.py) > gpurun_out/r02b_parity.txt 2>/dev/null
