@@ -326,7 +326,7 @@ def bench_f16(sd_np, dev, batch=256, steps=10, warmup=2):
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100, help="timed steps (default 100: >= 5 s of timed region)")
+    ap.add_argument("--steps", type=int, default=160, help="timed steps (default 160: >= 5 s of timed region at 35 ms per step)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch-per-gpu", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
