@@ -240,13 +240,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 
     // DMA plan of the halo: slot s = r*NT + tid -> (row, pixel, channel half); byte offsets into the current source, OOB = zeros
     unsigned hcur[HR];                                  // byte offsets inside the source image(s), OOB = padding
-    auto plan = [&](const ConvSrc &s) {
+    auto plan = [&](const ConvSrc &s, int r0 = 0, int r1 = HR) {
         // LEAN variants: thread id rebuilt from the lane id and the plan of the second source kept inside the loop (the empty
         // asm stops its hoisting), so that neither survives the K loop in registers
         int t_ = LEAN ? wave * 64 + lane_id() : tid;
         if constexpr (LEAN) asm volatile("" : "+v"(t_));
 #pragma unroll
         for (int r = 0; r < HR; ++r) {
+            if (r < r0 || r >= r1) continue;
             const int sl = r * NT + t_;
             int row = sl / RSL;                           // row r starts at slot RSL*r + (r >> 2)
             if (row * RSL + (row >> 2) > sl) --row;
@@ -261,7 +262,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                           ? (unsigned)((y * s.W + x) * 8 + half * 4 + second * s.C * s.H * s.W) * 4u : OOB;   // C8 layout
         }
     };
-    plan(p.s0);
+#ifndef W4_EARLY_HALO
+#define W4_EARLY_HALO 1
+#endif
+    if (!W4_EARLY_HALO) plan(p.s0);
     // descriptor of the current source: the image of clip n (pair mode: clips n, n + 1); soff walks its 8-channel blocks
     auto src_rsrc = [&](const ConvSrc &s) {
         const unsigned img = (unsigned)(s.C * s.H * s.W) * 4u;
@@ -297,6 +301,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     } while (0)
 #define W4_U_END() usoff += USLOTS * 16
     static_assert(HR == 5 && UR == 5, "W4_PLACE and the vmcnt immediates below assume five pieces per pass");
+    // The halo pieces of chunk 0 go out one by one as their slots are planned (the plan is ~50 instructions per piece): the
+    // first bytes are on their way ~2000 clocks before the last piece is issued.  (Chunk 0 always comes from the first source.)
+    if (W4_EARLY_HALO) {
+#pragma unroll
+        for (int k = 0; k < HR; ++k) {
+            plan(p.s0, k, k + 1);
+            W4_HALO_PIECE(k, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        W4_HALO_END();
+    }
 
     // after the epilogue's exchange this wave finishes cout block jh of its tile block
     const float bias_pre = LEAN ? 0.f : p.bias[ct * 32 + 16 * jh + ti];
@@ -315,10 +330,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int a_hi = a_lo + 4;                              // rows 4-5: the next group of four halo rows
     const int b_lane = (jh * 9 * 2 * 64 + lane) * 4;        // U slab [jh][group of 2 positions][pass][q][cout%16][pos%2][cout block]
 
-    W4_HALO_BEGIN(0);
+    if (!W4_EARLY_HALO) {
+        W4_HALO_BEGIN(0);
 #pragma unroll
-    for (int k = 0; k < HR; ++k) W4_HALO_PIECE(k, 0);
-    W4_HALO_END();
+        for (int k = 0; k < HR; ++k) W4_HALO_PIECE(k, 0);
+        W4_HALO_END();
+    }
 #ifdef ADN_EXPERIMENTS
     tlb = __builtin_amdgcn_s_memtime();                 // first copies issued
 #endif
