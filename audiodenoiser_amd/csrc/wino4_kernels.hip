@@ -44,6 +44,13 @@ typedef const volatile f32x4 __attribute__((address_space(3))) lds4_cv_f32x4;
 namespace {
 
 constexpr int KC = 8;                        // input channels per chunk
+// Build-time variants (tools/wino4_variants.sh passes -D switches to an experiments build; the defaults are the measured best)
+#ifndef W4_EARLY_HALO                         // 1: the first chunk's halo pieces go out one by one as their slots are planned
+#define W4_EARLY_HALO 1
+#endif
+#ifndef W4_EPI_FAST                           // 1: tile blocks wholly inside the image store without bounds checks
+#define W4_EPI_FAST 1
+#endif
 #ifndef W4_TPIN                               // 1: the whole input transform of a pass in front of its first MFMA (below)
 #define W4_TPIN 1
 #endif
@@ -262,9 +269,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                           ? (unsigned)((y * s.W + x) * 8 + half * 4 + second * s.C * s.H * s.W) * 4u : OOB;   // C8 layout
         }
     };
-#ifndef W4_EARLY_HALO
-#define W4_EARLY_HALO 1
-#endif
     if (!W4_EARLY_HALO) plan(p.s0);
     // descriptor of the current source: the image of clip n (pair mode: clips n, n + 1); soff walks its 8-channel blocks
     auto src_rsrc = [&](const ConvSrc &s) {
@@ -632,9 +636,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     ? static_cast<float *>(p.pool) + (size_t)nb * Hp * Wp * p.Cout + act_off<float>(p.Cout, (long)Hp * Wp, 0, col)
                     : nullptr;
     const int gy0e = ty * REG + 16 * by + 4 * eq, gx0e = tx * REG + (pair ? 0 : 16 * bx);
-#ifndef W4_EPI_FAST
-#define W4_EPI_FAST 1
-#endif
     const bool interior = W4_EPI_FAST && clip_ok && ty * REG + 16 * by + 16 <= p.H && gx0e + 16 <= p.W;       // wave-uniform
     auto finish = [&](auto interior_tag) {
         constexpr bool INT = decltype(interior_tag)::value;
@@ -751,45 +752,17 @@ hipError_t launch_wino4_conv(ConvKind kind, const ConvArgs &a, hipStream_t st)
         attr_mask.fetch_or(bit, std::memory_order_release);
     }
 #ifdef ADN_EXPERIMENTS
-    static const int place = []() { const char *e = std::getenv("ADN_W4_PLACE"); return e ? std::atoi(e) : -1; }();
-    if (place >= 0 && !a2.ablate) {
-        const void *f = nullptr;
-        switch (place * 4 + (int)kind) {
-#define W4_PL(n) case n * 4 + 0: f = reinterpret_cast<const void *>(wino4_conv_f32<CONV3X3_RELU, 0, n>); break; \
-                 case n * 4 + 1: f = reinterpret_cast<const void *>(wino4_conv_f32<CONV3X3_RELU_POOL, 0, n>); break; \
-                 case n * 4 + 3: f = reinterpret_cast<const void *>(wino4_conv_f32<CONV3X3_RELU_DOT, 0, n>); break;
-            W4_PL(0) W4_PL(1) W4_PL(2) W4_PL(3) W4_PL(4) W4_PL(5) W4_PL(6) W4_PL(7)
-            W4_PL(8) W4_PL(9) W4_PL(10) W4_PL(11) W4_PL(12) W4_PL(13) W4_PL(14) W4_PL(15)
-#undef W4_PL
-        default: return hipErrorInvalidValue;
-        }
-        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
-        if (e != hipSuccess) return e;
-        void *args[] = {&a2};
-        return hipLaunchKernel(f, dim3((unsigned)nwg), dim3(NT), args, LDS_BYTES, st);
-    }
-    if (a2.ablate) {
-        const void *f = nullptr;
-        switch (a2.ablate) {
-#define W4_ABL(n) case n: f = reinterpret_cast<const void *>(wino4_conv_f32<CONV3X3_RELU, n>); break;
-            W4_ABL(1) W4_ABL(2) W4_ABL(4) W4_ABL(8) W4_ABL(16) W4_ABL(9) W4_ABL(18) W4_ABL(19) W4_ABL(27) W4_ABL(32) W4_ABL(64)
-            W4_ABL(128) W4_ABL(256) W4_ABL(2048) W4_ABL(2067) W4_ABL(4096) W4_ABL(8192)
-#undef W4_ABL
-        default: return hipErrorInvalidValue;
-        }
-        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
-        if (e != hipSuccess) return e;
-        void *args[] = {&a2};
-        return hipLaunchKernel(f, dim3((unsigned)nwg), dim3(NT), args, LDS_BYTES, st);
-    }
-#endif
-#ifdef ADN_EXPERIMENTS
     static const bool timeline = std::getenv("ADN_W4_TIMELINE") != nullptr;
     if (timeline && kind != CONV3X3_RELU_DOT) {
         const size_t bytes = (size_t)nwg * 8 * sizeof(unsigned long long);
         if (hipMalloc(&a2.dbg, bytes) != hipSuccess) return hipErrorOutOfMemory;
         (void)hipMemset(a2.dbg, 0, bytes);
-        if (kind == CONV3X3_RELU_POOL)
+        if (a2.ablate == 128 && kind == CONV3X3_RELU) {   // copies without memory traffic (every lane out of range): the prologue's memory share
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_conv_f32<CONV3X3_RELU, 128>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((wino4_conv_f32<CONV3X3_RELU, 128>), dim3((unsigned)nwg), dim3(NT), LDS_BYTES, st, a2);
+        } else if (kind == CONV3X3_RELU_POOL)
             hipLaunchKernelGGL(wino4_conv_f32<CONV3X3_RELU_POOL>, dim3((unsigned)nwg), dim3(NT), LDS_BYTES, st, a2);
         else
             hipLaunchKernelGGL(wino4_conv_f32<CONV3X3_RELU>, dim3((unsigned)nwg), dim3(NT), LDS_BYTES, st, a2);
@@ -828,6 +801,39 @@ hipError_t launch_wino4_conv(ConvKind kind, const ConvArgs &a, hipStream_t st)
                              "launch span %.0f clocks; prologue = decode %.0f + copies issued %.0f + landed %.0f + barrier\n", a2.H, a2.W, a2.nchunk, a2.Cout, recs.size(), ncu, pro / nr, loop / nr,
                      loop / nr / a2.nchunk, epi / nr, drain / nr, ngap ? gap / ngap : 0.0, span, dec / nr, iss / nr, land / nr);
         return hipGetLastError();
+    }
+#endif
+#ifdef ADN_EXPERIMENTS
+    static const int place = []() { const char *e = std::getenv("ADN_W4_PLACE"); return e ? std::atoi(e) : -1; }();
+    if (place >= 0 && !a2.ablate) {
+        const void *f = nullptr;
+        switch (place * 4 + (int)kind) {
+#define W4_PL(n) case n * 4 + 0: f = reinterpret_cast<const void *>(wino4_conv_f32<CONV3X3_RELU, 0, n>); break; \
+                 case n * 4 + 1: f = reinterpret_cast<const void *>(wino4_conv_f32<CONV3X3_RELU_POOL, 0, n>); break; \
+                 case n * 4 + 3: f = reinterpret_cast<const void *>(wino4_conv_f32<CONV3X3_RELU_DOT, 0, n>); break;
+            W4_PL(0) W4_PL(1) W4_PL(2) W4_PL(3) W4_PL(4) W4_PL(5) W4_PL(6) W4_PL(7)
+            W4_PL(8) W4_PL(9) W4_PL(10) W4_PL(11) W4_PL(12) W4_PL(13) W4_PL(14) W4_PL(15)
+#undef W4_PL
+        default: return hipErrorInvalidValue;
+        }
+        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e != hipSuccess) return e;
+        void *args[] = {&a2};
+        return hipLaunchKernel(f, dim3((unsigned)nwg), dim3(NT), args, LDS_BYTES, st);
+    }
+    if (a2.ablate) {
+        const void *f = nullptr;
+        switch (a2.ablate) {
+#define W4_ABL(n) case n: f = reinterpret_cast<const void *>(wino4_conv_f32<CONV3X3_RELU, n>); break;
+            W4_ABL(1) W4_ABL(2) W4_ABL(4) W4_ABL(8) W4_ABL(16) W4_ABL(9) W4_ABL(18) W4_ABL(19) W4_ABL(27) W4_ABL(32) W4_ABL(64)
+            W4_ABL(128) W4_ABL(256) W4_ABL(2048) W4_ABL(2067) W4_ABL(4096) W4_ABL(8192)
+#undef W4_ABL
+        default: return hipErrorInvalidValue;
+        }
+        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e != hipSuccess) return e;
+        void *args[] = {&a2};
+        return hipLaunchKernel(f, dim3((unsigned)nwg), dim3(NT), args, LDS_BYTES, st);
     }
 #endif
     static_assert(8 * (256 * 17 + 32) * sizeof(float) <= LDS_BYTES, "staging of the fused 1x1 epilogue must fit the images");
