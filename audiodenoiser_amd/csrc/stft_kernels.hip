@@ -722,11 +722,13 @@ hipError_t launch_stft_mag(const float *audio, int n_clips, long L, int n_fft, i
         }
     }
     switch (n_fft) {
+#ifdef ADN_EXPERIMENTS                  // n_fft <= 1024 reaches the workgroup-synchronous kernel only with ADN_STFT_VARIANT=0 (A/B runs)
         case 64: return launch_m<32>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st);
         case 128: return launch_m<64>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st);
         case 256: return launch_m<128>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st);
         case 512: return launch_m<256>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st);
         case 1024: return launch_m<512>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st);
+#endif
         case 2048: return launch_m<1024>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st);
         case 4096: return launch_m<2048>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st);
         default: return hipErrorInvalidValue;

@@ -6,6 +6,7 @@ rank; RCCL on ROCm via ``torch.distributed`` backend "nccl", gloo in the CPU tes
 """
 from __future__ import annotations
 
+import inspect
 import os
 
 import torch
@@ -36,12 +37,20 @@ def init_from_env(backend: str | None = None):
             # one process per GPU: bind this rank to its device BEFORE the communicator exists, so that barriers and
             # collectives never guess a device (RCCL would otherwise start every rank on device 0)
             torch.cuda.set_device(local_rank)
-            kwargs["device_id"] = torch.device("cuda", local_rank)
-        try:
-            dist.init_process_group(backend, rank=rank, world_size=world, **kwargs)
-        except TypeError:                                  # torch without the device_id keyword
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            # decided from the signature, not by catching TypeError: a TypeError raised inside a half-finished
+            # initialisation must surface as itself, not as the retry's "already initialized"
+            if "device_id" in inspect.signature(dist.init_process_group).parameters:
+                kwargs["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend, rank=rank, world_size=world, **kwargs)
     return rank, local_rank, world
+
+
+def rank() -> int:
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def world_size() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
 def gather_per_clip(local: torch.Tensor) -> torch.Tensor:

@@ -32,15 +32,23 @@ def winograd_tile(launch: dict, mode: str = "auto") -> int:
 
 def _wino4_tiled_area(h: int, w: int) -> int:
     """Pixels per clip the F(4x4,3x3) workgroup tiles cover: 32x32 tiles, or -- images at most 16 pixels wide, "pair mode":
-    a tile holds the same 32 rows of two clips side by side -- 32 rows x 16 columns."""
+    a tile holds the same 32 rows of two clips side by side -- 32 rows x 16 columns.  (What ``wino4_applicable`` weighs.)"""
     return _ceil_to(h, 32) * 16 if w <= 16 else _ceil_to(h, 32) * _ceil_to(w, 32)
+
+
+def _wino4_computed_area(h: int, w: int) -> int:
+    """Pixels per clip the F(4x4,3x3) kernel runs MFMAs for: a workgroup tile is 2x2 blocks of 16x16 pixels and a block that
+    lies wholly outside the image does no arithmetic (``active`` in csrc/wino4_kernels.hip), so the image is padded to
+    multiples of 16, not 32 -- 528 rows for H = 513, not 544."""
+    return _ceil_to(h, 16) * 16 if w <= 16 else _ceil_to(h, 16) * _ceil_to(w, 16)
 
 
 def executed_mfma_flops(launch: dict, algo: str, wino_mode: str = "auto") -> float:
     """Matrix-core FLOPs one launch EXECUTES per sample, padded tiles counted (what `roofline.frac` is made of).
 
     ``algo``: "winograd" (fp32 default: wino4_conv_f32 = F(4x4,3x3), 36 multiply-adds per 4x4 output tile and (cin, cout)
-    pair = 4.5 FLOP per padded output pixel on 32x32 tiles, where ``winograd_tile`` says so; wino_conv_dma_f32 =
+    pair = 4.5 FLOP per computed output pixel -- the 16x16-pixel blocks of its 32x32 tiles that touch the image --, where
+    ``winograd_tile`` says so; wino_conv_dma_f32 =
     F(2x2,3x3), 16 multiply-adds per 2x2 tile = 8 FLOP per padded pixel on 16x16 tiles, elsewhere), "direct"
     (conv_mfma<float>: TH x 16 tiles with TH = 16 for the 64-channel layers and 8 otherwise, 18 FLOP per pixel) or
     "direct_f16" (conv_dma<_Float16>: 32 x 16 tiles for every layer).  Transposed convolutions run
@@ -54,7 +62,7 @@ def executed_mfma_flops(launch: dict, algo: str, wino_mode: str = "auto") -> flo
         return 2.0 * cin * 4 * cout * _ceil_to(h, 8) * _ceil_to(w, 16)
     if algo == "winograd":
         if winograd_tile(launch, wino_mode) == 4:
-            return 4.5 * cin * cout * _wino4_tiled_area(h, w)
+            return 4.5 * cin * cout * _wino4_computed_area(h, w)
         return 8.0 * cin * cout * _ceil_to(h, 16) * _ceil_to(w, 16)
     th = 32 if algo == "direct_f16" else (16 if cout == 64 else 8)
     return 18.0 * cin * cout * _ceil_to(h, th) * _ceil_to(w, 16)

@@ -25,7 +25,16 @@ everywhere, ADN_CONV_ALGO=direct selects the direct implicit-GEMM kernel conv_mf
   correction), read from profiles/pmc_traffic.json ONLY if that file was produced from this very build of libadn.so
   (source digest recorded in it); null otherwise.
 
+Batch per GPU: 64 at N = 1 (BASELINE configs[1], the config `metric` is quoted on); 256 when launched on more than one
+rank (BASELINE configs[3]: batch 2048 sharded over 8 GPUs = 256 clips per GPU; weak scaling, so 2 and 4 ranks also run 256
+per GPU).  The N = 1 line carries `fp32_b256` -- the same step at 256 clips on one GPU -- which is the per-GPU figure the
+N > 1 values are to be compared with.  Every line carries `ranks`: how many ranks the gathered tensor held, each rank's own
+time for the K steps (min / max) and the all-gather's own time.
+
 Sub-benchmarks in the same JSON line (rank 0, N = 1 only; --no-extras skips them):
+  `fp32_b256`  the main step at batch 256 (north_star's batch, one rank's shard of configs[3]).
+  `b1`    single-clip latency at 513x256 and the reference's own shapes (257x188 whole test set of 5 clips as test.py:112-113
+          runs it, 256x64 at the training batch of 16), default kernels and the single-clip serving switches.
   `stft`  BASELINE configs[2]: 10 000 clips x 132 300 samples, n_fft 1024, hop 256, centred; HBM roofline of
           stft_wave_kernel (algorithmic bytes = audio read once + magnitudes written once = 1 590 084 B per clip),
           with the C oracle's STFT timed beside it.
@@ -323,16 +332,199 @@ def bench_f16(sd_np, dev, batch=256, steps=10, warmup=2):
     return res
 
 
+def default_batch_per_gpu(world: int) -> int:
+    """BASELINE configs[1] (batch 64 on one GPU) at N = 1; configs[3] (batch 2048 over 8 GPUs = 256 clips per GPU) on more
+    than one rank -- weak scaling: the same 256 per GPU at 2 and 4 ranks."""
+    return 64 if world <= 1 else 256
+
+
+def timed_region(step, steps: int, warmup: int, sync, device, on_timed_start=None, gather_probe=None):
+    """The contract's timing: `warmup` untimed steps, barrier + sync, EXACTLY `steps` steps, sync + barrier; the time is the
+    MAX over ranks.  `step()` returns the gathered per-clip tensor of the step (rank order).  `sync()` waits for this rank's
+    device work (torch.cuda.synchronize on a GPU, a no-op in the CPU test).  Also measured, outside the timed region: each
+    rank's own time for the K steps (between its own sync points), how many ranks the collective really spans (every rank
+    contributes its id to a gathered tensor) and the all-gather's own time (`gather_probe()` = one all-gather of the step's
+    payload, timed over 20 calls).  Used by main() and, with a stub step on gloo, by tests/test_host_logic.py."""
+    from audiodenoiser_amd import distributed as D
+    rank = D.rank()
+    allv = None
+    for _ in range(warmup):
+        allv = step()
+    if on_timed_start is not None:
+        on_timed_start()
+    D.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        allv = step()
+    sync()
+    own = time.perf_counter() - t0
+    D.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = D.max_over_ranks(elapsed, device)
+    per_rank = D.gather_per_clip(torch.tensor([float(rank), own], dtype=torch.float64, device=device)).reshape(-1, 2).cpu()
+    ids = sorted(int(v) for v in per_rank[:, 0].tolist())
+    own_ms = (per_rank[:, 1] / steps * 1e3).tolist()
+    gather_ms = None
+    if gather_probe is not None:
+        for _ in range(3):
+            gather_probe()
+        sync()
+        D.barrier()
+        g0 = time.perf_counter()
+        for _ in range(20):
+            gather_probe()
+        sync()
+        gather_ms = D.max_over_ranks((time.perf_counter() - g0) / 20 * 1e3, device)
+    return {"elapsed_s": elapsed, "last": allv,
+            "ranks": {"ranks_seen": len(set(ids)), "rank_ids": ids, "world_size": D.world_size(),
+                      "rank_ms_per_step_min": round(min(own_ms), 3), "rank_ms_per_step_max": round(max(own_ms), 3),
+                      "allgather_ms": None if gather_ms is None else round(gather_ms, 4),
+                      "allgather_payload_floats_per_rank": None}}
+
+
+def assemble_line(elapsed_s: float, steps: int, warmup: int, world: int, batch_per_gpu: int, dtype: str, ranks: dict,
+                  extra_config=None) -> dict:
+    """The contract's JSON line (without the roofline / sub-benchmark objects main() adds on a GPU)."""
+    f16 = dtype == "f16"
+    frames = batch_per_gpu * world * T_FRAMES * steps
+    cfg = ("BASELINE configs[3]: batch=%d synthetic 513x256 fp32 spectrograms sharded over %d MI355X (%d clips per GPU)"
+           % (batch_per_gpu * world, world, batch_per_gpu)) if world > 1 else \
+          ("BASELINE configs[1]: batch=%d synthetic 513x256 fp32 spectrograms on one MI355X" % batch_per_gpu)
+    config = {"workload": cfg + ", full U-Net forward "
+                          + ("[fp16 storage + fp16 MFMA inside, BASELINE configs[4]] " if f16 else "")
+                          + "+ per-clip perceptual loss" + (" + RCCL all-gather of the per-clip values" if world > 1 else ""),
+              "batch_per_gpu": batch_per_gpu, "global_batch": batch_per_gpu * world, "freq_bins": F_BINS, "frames": T_FRAMES,
+              "parallelism": f"clips sharded over {world} rank(s), weights replicated, no data-path collective",
+              "timed_region_s": round(elapsed_s, 3)}
+    if extra_config:
+        config.update(extra_config)
+    return {"metric": "spectrogram frames/sec (forward), 513x256 fp32",
+            "value": round(frames / elapsed_s, 1),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": steps,
+            "warmup": warmup,
+            "ms_per_step": round(elapsed_s / steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": dtype,
+            "data": "synthetic",
+            "config": config,
+            "ranks": ranks}
+
+
+def kernel_names(f16: bool):
+    """(algo, peak, kernel description, PMC traffic key, Winograd tile mode) of the dominant 3x3 kernel of this process's
+    handles (ADN_CONV_ALGO / ADN_WINO_TILE are read by libadn when a handle is created)."""
+    from audiodenoiser_amd.roofline import PEAK_MFMA_F16_TFLOPS, PEAK_MFMA_F32_TFLOPS
+    direct = f16 or not bool(net_uses_winograd())
+    algo = "direct_f16" if f16 else ("direct" if direct else "winograd")
+    peak = PEAK_MFMA_F16_TFLOPS if f16 else PEAK_MFMA_F32_TFLOPS
+    wmode = wino_tile_mode()
+    kname = ("conv_dma<_Float16, 32, 64, ...> (LDS-DMA staged direct implicit GEMM, fp16 MFMA)" if f16 else
+             "conv_mfma<float> (direct implicit GEMM, fp32 MFMA)" if direct else
+             "wino_conv_dma_f32 (Winograd F(2x2,3x3), fp32 MFMA v_mfma_f32_16x16x4_f32)" if wmode == "2" else
+             "wino4_conv_f32 (Winograd F(4x4,3x3), fp32 MFMA v_mfma_f32_16x16x4_f32)")
+    tkey = ("conv_mfma_f16" if f16 else "conv_mfma_f32" if direct else
+            "wino_conv_dma_f32" if wmode == "2" else "wino4_conv_f32")
+    return algo, peak, kname, tkey, wmode
+
+
+def bench_fp32_b256(sd_np, dev, batch=256, steps=10, warmup=2):
+    """The headline step at north_star's batch (256 clips = one rank's shard of BASELINE configs[3]) on this one GPU."""
+    from audiodenoiser_amd import _lib
+    from audiodenoiser_amd.loss import perceptual_loss_per_clip
+    net = make_net(sd_np, dev, "f32")
+    g = torch.Generator(device=dev).manual_seed(0)
+    x = torch.rand((batch, 1, F_BINS, T_FRAMES), generator=g, device=dev) * 4.0
+    target = torch.rand((batch, 1, F_BINS, T_FRAMES), generator=g, device=dev) * 4.0
+    L = _lib.load()
+    with torch.no_grad():
+        for _ in range(warmup):
+            loss = perceptual_loss_per_clip(net(x), target)
+        _lib.check(L.adn_unet_set_timing(net._handle, steps), "adn_unet_set_timing")
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = perceptual_loss_per_clip(net(x), target)
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+    assert bool(torch.isfinite(loss).all())
+    ms_mean = launch_timings(net, steps)
+    algo, peak, kname, tkey, wmode = kernel_names(False)
+    roof = conv_roofline(ms_mean, batch, algo, peak, kname, tkey, wmode)
+    res = {"workload": f"batch={batch} synthetic 513x256 fp32 spectrograms on one MI355X (north_star's batch; the per-GPU "
+                       "shard of BASELINE configs[3]), full U-Net forward + per-clip perceptual loss",
+           "steps": steps, "warmup": warmup, "dtype": "f32", "ms_per_step": round(el / steps * 1e3, 3),
+           "value": round(batch * T_FRAMES * steps / el, 1), "unit": "frames/s",
+           "frac": roof["frac"], "roofline": {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "avg_launch_ms")},
+           "forward_kernel_ms": round(float(ms_mean.sum()), 3)}
+    net._release()
+    del net, x, target
+    torch.cuda.empty_cache()
+    return res
+
+
+def bench_latency(sd_np, dev, iters=30):
+    """Single-clip / small-batch latency: BASELINE configs[0] is one clip through the forward (test.py:112-113 runs its whole
+    test set -- 5 clips of 257x188 -- as one batch; train.py:84 validates at batch 16 of 256x64).  Default kernels, and the
+    serving switches libadn reads when a handle is created (ADN_WINO_TILE=2 + ADN_WINO_SPLITK=1: finer F(2x2,3x3) grid and
+    split-K, which fill the chip at one clip; they change the summation order, so they are opt-in)."""
+    shapes = (("513x256_b1", 1, F_BINS, T_FRAMES), ("257x188_b1", 1, 257, 188), ("257x188_b5_test_py", 5, 257, 188),
+              ("256x64_b16_train_py", 16, 256, 64))
+
+    def run(env):
+        saved = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            net = make_net(sd_np, dev, "f32")
+            out = {}
+            with torch.no_grad():
+                for name, b, f, t in shapes:
+                    x = torch.rand((b, 1, f, t), device=dev) * 4.0
+                    for _ in range(3):
+                        net(x)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    torch.cuda.synchronize(dev)
+                    e0.record()
+                    for _ in range(iters):
+                        y = net(x)
+                    e1.record()
+                    torch.cuda.synchronize(dev)
+                    assert bool(torch.isfinite(y).all())
+                    ms = e0.elapsed_time(e1) / iters
+                    out[name] = {"ms_per_forward": round(ms, 4), "frames_per_s": round(b * t / (ms * 1e-3), 1)}
+            net._release()
+            return out
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+
+    res = {"what": "forward only (no loss), back-to-back calls on one stream, HIP events; default = the kernels of the "
+                   "headline metric; serving = ADN_WINO_TILE=2 ADN_WINO_SPLITK=1 (F(2x2,3x3) grid + split-K)",
+           "default": run({}), "serving": run({"ADN_WINO_TILE": "2", "ADN_WINO_SPLITK": "1"})}
+    torch.cuda.empty_cache()
+    return res
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=160, help="timed steps (default 160: >= 5 s of timed region at 35 ms per step)")
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch-per-gpu", type=int, default=64)
+    ap.add_argument("--batch-per-gpu", type=int, default=None,
+                    help="default: 64 on one GPU (BASELINE configs[1]), 256 on more than one rank (configs[3] = 2048 / 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the stft (configs[2]) and f16 (configs[4]) sub-benchmarks")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the sub-benchmarks (stft = configs[2], f16 = configs[4], fp32_b256, b1)")
     ap.add_argument("--stft-steps", type=int, default=20)
     ap.add_argument("--f16-steps", type=int, default=10)
+    ap.add_argument("--b256-steps", type=int, default=10)
     ap.add_argument("--no-stft-cpu", action="store_true", help="skip the C-oracle STFT timing inside the stft sub-benchmark")
     ap.add_argument("--no-finite-check", action="store_true",
                     help="timing experiments of an ADN_BUILD_EXPERIMENTS library only (ablated kernels produce garbage)")
@@ -343,7 +535,6 @@ def main() -> None:
     from audiodenoiser_amd import _lib
     from audiodenoiser_amd import distributed as D
     from audiodenoiser_amd.loss import perceptual_loss_per_clip
-    from audiodenoiser_amd.roofline import PEAK_MFMA_F16_TFLOPS, PEAK_MFMA_F32_TFLOPS
     from audiodenoiser_amd.weights import make_state_dict
 
     if not torch.cuda.is_available():
@@ -360,7 +551,7 @@ def main() -> None:
     net = make_net(sd_np, dev, args.dtype)
     f16 = args.dtype == "f16"
 
-    b = args.batch_per_gpu
+    b = args.batch_per_gpu if args.batch_per_gpu else default_batch_per_gpu(world)
     g = torch.Generator(device=dev).manual_seed(rank)                 # per-rank shard of the global batch
     x = torch.rand((b, 1, F_BINS, T_FRAMES), generator=g, device=dev) * 4.0      # resident in HBM
     target = torch.rand((b, 1, F_BINS, T_FRAMES), generator=g, device=dev) * 4.0
@@ -371,63 +562,36 @@ def main() -> None:
         return D.gather_per_clip(loss.reshape(-1))
 
     L = _lib.load()
+    payload = torch.zeros(4 * b, dtype=torch.float32, device=dev)
     with torch.no_grad():
-        for _ in range(args.warmup):
-            allv = step()
-        _lib.check(L.adn_unet_set_timing(net._handle, args.steps), "adn_unet_set_timing")
-        D.barrier()
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            allv = step()
-        torch.cuda.synchronize(dev)
-        D.barrier()
-        elapsed = time.perf_counter() - t0
-    elapsed = D.max_over_ranks(elapsed, dev)
+        tr = timed_region(step, args.steps, args.warmup, lambda: torch.cuda.synchronize(dev), dev,
+                          on_timed_start=lambda: _lib.check(L.adn_unet_set_timing(net._handle, args.steps), "adn_unet_set_timing"),
+                          gather_probe=(lambda: D.gather_per_clip(payload)) if world > 1 else None)
+    elapsed, allv = tr["elapsed_s"], tr["last"]
+    tr["ranks"]["allgather_payload_floats_per_rank"] = 4 * b
     assert allv.numel() == 4 * b * world and (args.no_finite_check or bool(torch.isfinite(allv).all()))
+    assert tr["ranks"]["ranks_seen"] == world, tr["ranks"]
     ms_mean = launch_timings(net, args.steps)      # per-launch durations of the timed steps (events inside libadn)
 
     if rank == 0:
-        direct = f16 or not bool(net_uses_winograd())
-        algo = "direct_f16" if f16 else ("direct" if direct else "winograd")
-        peak = PEAK_MFMA_F16_TFLOPS if f16 else PEAK_MFMA_F32_TFLOPS
-        wmode = wino_tile_mode()
-        kname = ("conv_dma<_Float16, 32, 64, ...> (LDS-DMA staged direct implicit GEMM, fp16 MFMA)" if f16 else
-                 "conv_mfma<float> (direct implicit GEMM, fp32 MFMA)" if direct else
-                 "wino_conv_dma_f32 (Winograd F(2x2,3x3), fp32 MFMA v_mfma_f32_16x16x4_f32)" if wmode == "2" else
-                 "wino4_conv_f32 (Winograd F(4x4,3x3), fp32 MFMA v_mfma_f32_16x16x4_f32)")
-        tkey = ("conv_mfma_f16" if f16 else "conv_mfma_f32" if direct else
-                "wino_conv_dma_f32" if wmode == "2" else "wino4_conv_f32")
-        frames = b * world * T_FRAMES * args.steps
-        out = {
-            "metric": "spectrogram frames/sec (forward), 513x256 fp32",
-            "value": round(frames / elapsed, 1),
-            "unit": "frames/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": args.dtype,
-            "data": "synthetic",
-            "config": {"workload": f"batch={b} per GPU synthetic 513x256 fp32 spectrograms, full U-Net forward "
-                                   + ("[fp16 storage + fp16 MFMA inside, BASELINE configs[4]] " if f16 else "")
-                                   + "(BASELINE configs[1]) + per-clip perceptual loss" + (" + all-gather" if world > 1 else ""),
-                       "batch_per_gpu": b, "global_batch": b * world, "freq_bins": F_BINS, "frames": T_FRAMES,
-                       "parallelism": f"clips sharded over {world} rank(s), weights replicated",
-                       "timed_region_s": round(elapsed, 3), "lib_digest": lib_digest()[:12]},
-            "roofline": conv_roofline(ms_mean, b, algo, peak, kname, tkey, wmode),
-            "forward": forward_summary(ms_mean, b, algo, peak, wmode),
-        }
+        algo, peak, kname, tkey, wmode = kernel_names(f16)
+        out = assemble_line(elapsed, args.steps, args.warmup, world, b, args.dtype, tr["ranks"],
+                            {"lib_digest": lib_digest()[:12]})
+        out["roofline"] = conv_roofline(ms_mean, b, algo, peak, kname, tkey, wmode)
+        out["forward"] = forward_summary(ms_mean, b, algo, peak, wmode)
+        if world > 1:
+            out["config"]["compare_with"] = ("the N = 1 line's fp32_b256.value (the same 256 clips per GPU on one GPU); the N = 1 "
+                                             "headline value is BASELINE configs[1] at 64 clips")
         del allv
         if world == 1 and not args.no_extras:
             net._workspace = None
+            del x, target
             torch.cuda.empty_cache()
             out["stft"] = bench_stft(dev, steps=args.stft_steps, cpu_clips=0 if args.no_stft_cpu else 4096)
             if not f16:
                 out["f16"] = bench_f16(sd_np, dev, steps=args.f16_steps)
+                out["fp32_b256"] = bench_fp32_b256(sd_np, dev, steps=args.b256_steps)
+                out["b1"] = bench_latency(sd_np, dev)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(sd_np)
         print(json.dumps(out), flush=True)
