@@ -3,7 +3,8 @@
 Every ``csrc/*.hip`` is compiled to an object (in parallel, per-file flags in ``FILE_FLAGS``) and the objects are
 linked into ``audiodenoiser_amd/_lib/libadn.so`` (git-ignored, shipped to the GPU box with the working tree).  A
 content hash of the sources and flags is stored next to the library so that a copied tree with fresh mtimes does
-not trigger a rebuild.
+not trigger a rebuild (stamp = two lines: the code digest that identifies the build in bench.py / profiles, and the
+raw-bytes digest that decides about rebuilding).
 """
 from __future__ import annotations
 
@@ -48,17 +49,20 @@ def _sources():
 
 
 def _strip_comments(text: str) -> str:
-    """C / C++ source with comments removed and runs of whitespace collapsed (string and character literals kept), so that
-    the digest below identifies the CODE of a build: editing a comment does not orphan profiles/pmc_traffic.json."""
-    out = []
+    """C / C++ source with comments removed and whitespace normalised, so that the digest below identifies the CODE of a
+    build: editing a comment or re-wrapping a line does not orphan profiles/pmc_traffic.json.  String and character literals
+    are kept byte for byte (spacing inside them is code), and a preprocessor directive keeps the newline that ends it
+    (moving a token across the end of a ``#define`` changes the program)."""
+    out, lits = [], []
     i, n = 0, len(text)
     while i < n:
         c = text[i]
-        if c in "\"'":                                   # literal: copy verbatim up to the closing quote
+        if c in "\"'":                                   # literal: set aside verbatim up to the closing quote
             j = i + 1
             while j < n and text[j] != c:
                 j += 2 if text[j] == "\\" else 1
-            out.append(text[i:j + 1])
+            lits.append(text[i:j + 1])
+            out.append(f"\x00{len(lits) - 1}\x00")
             i = j + 1
         elif text.startswith("//", i):
             j = text.find("\n", i)
@@ -72,19 +76,59 @@ def _strip_comments(text: str) -> str:
         else:
             out.append(c)
             i += 1
-    return " ".join("".join(out).split())
+    parts, pending = [], ""
+    for line in "".join(out).split("\n"):
+        line = pending + line
+        if line.rstrip().endswith("\\"):                   # continued line (multi-line #define)
+            pending = line.rstrip()[:-1] + " "
+            continue
+        pending = ""
+        norm = " ".join(line.split())
+        if norm:
+            parts.append(norm + ("\n" if norm.startswith("#") else " "))
+    code = "".join(parts)
+    for k, lit in enumerate(lits):
+        code = code.replace(f"\x00{k}\x00", lit)
+    return code
+
+
+def _digest_files():
+    return _sources() + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(INCLUDE, "adn.h")]
+
+
+def _flags_tag() -> bytes:
+    return (ARCH + "|" + " ".join(_extra_flags()) + "|" + repr(sorted(FILE_FLAGS.items())) + "|" + " ".join(COMMON_FLAGS)).encode()
 
 
 def _digest() -> str:
+    """Digest of the CODE (comments and layout stripped) + flags: the identity bench.py and profiles/pmc_traffic.json use."""
     h = hashlib.sha256()
-    for p in _sources() + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(INCLUDE, "adn.h")]:
+    for p in _digest_files():
         h.update(os.path.basename(p).encode())
         with open(p, "r", encoding="utf-8") as f:
             h.update(_strip_comments(f.read()).encode())
-    h.update(ARCH.encode())
-    h.update(" ".join(_extra_flags()).encode())
-    h.update(repr(sorted(FILE_FLAGS.items())).encode())
+    h.update(_flags_tag())
     return h.hexdigest()
+
+
+def _raw_digest() -> str:
+    """Digest of the source BYTES + flags: what decides whether the in-tree library is rebuilt (any edit rebuilds)."""
+    h = hashlib.sha256()
+    for p in _digest_files():
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as f:
+            h.update(f.read())
+    h.update(_flags_tag())
+    return h.hexdigest()
+
+
+def code_digest_of_built_library() -> str:
+    """First line of the stamp written next to libadn.so: the code digest of the build that produced it ("" if none)."""
+    try:
+        with open(STAMP) as f:
+            return f.readline().strip()
+    except OSError:
+        return ""
 
 
 def hipcc_path():
@@ -95,7 +139,8 @@ def up_to_date() -> bool:
     if not (os.path.exists(LIB) and os.path.exists(STAMP)):
         return False
     with open(STAMP) as f:
-        return f.read().strip() == _digest()
+        lines = f.read().split()
+    return len(lines) == 2 and lines[1] == _raw_digest()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -136,7 +181,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
                     if os.path.exists(tmp):
                         os.remove(tmp)
             with open(STAMP + ".tmp", "w") as f:
-                f.write(_digest() + "\n")
+                f.write(_digest() + "\n" + _raw_digest() + "\n")
             os.replace(STAMP + ".tmp", STAMP)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)

@@ -792,8 +792,8 @@ int adn_per_clip_l1(const float *a, const float *b, int n_clips, long elems_per_
 
 int adn_perceptual_loss_workspace_bytes(int n_clips, int F, int T, size_t *bytes)
 {
-    if (!bytes || n_clips < 1 || F < 1 || T < 64 || T > adn::ADN_LOSS_MAX_T)
-        return fail(ADN_ERR_INVALID, "adn_perceptual_loss_workspace_bytes: need n_clips,F >= 1 and 64 <= T <= 6784");
+    if (!bytes || n_clips < 1 || F < 1 || T < adn::ADN_LOSS_MIN_T || T > adn::ADN_LOSS_MAX_T)
+        return fail(ADN_ERR_INVALID, "adn_perceptual_loss_workspace_bytes: need n_clips,F >= 1 and 32 <= T <= 6784");
     *bytes = adn::perceptual_loss_workspace_floats(n_clips, F, T) * sizeof(float);
     return ADN_OK;
 }
@@ -802,9 +802,13 @@ int adn_perceptual_loss(const float *pred, const float *target, int n_clips, int
                         size_t workspace_bytes, float *out, void *stream)
 {
     if (!pred || !target || !out) return fail(ADN_ERR_INVALID, "adn_perceptual_loss: null pointer");
-    if (n_clips < 1 || F < 1 || T < 64 || T > adn::ADN_LOSS_MAX_T || adn::perceptual_loss_lds_bytes(T) > adn::ADN_LOSS_MAX_LDS)
-        return fail(ADN_ERR_INVALID, "adn_perceptual_loss: need n_clips,F >= 1 and 64 <= T <= 6784 (the per-clip series, "
-                                     "trig tables and mel frames of one clip must fit the 160 KiB LDS of a CU)");
+    // T >= 32: the mel term's reflect padding of n_fft / 2 = 31 samples needs a longer series (torch.stft / torchaudio raise
+    // below that too: loss.py:39-41 with pad_mode "reflect")
+    if (n_clips < 1 || F < 1 || T < adn::ADN_LOSS_MIN_T || T > adn::ADN_LOSS_MAX_T ||
+        adn::perceptual_loss_lds_bytes(T) > adn::ADN_LOSS_MAX_LDS)
+        return fail(ADN_ERR_INVALID, "adn_perceptual_loss: need n_clips,F >= 1 and 32 <= T <= 6784 (reflect padding of the mel "
+                                     "term needs T > 31; the per-clip series, trig tables and mel frames of one clip must fit "
+                                     "the 160 KiB LDS of a CU)");
     const size_t need = adn::perceptual_loss_workspace_floats(n_clips, F, T) * sizeof(float);
     if (!workspace || workspace_bytes < need) return fail(ADN_ERR_WORKSPACE, "adn_perceptual_loss: workspace too small");
     ADN_HIP(adn::launch_perceptual_loss(pred, target, n_clips, F, T, static_cast<float *>(workspace), out,

@@ -145,6 +145,7 @@ size_t perceptual_loss_workspace_floats(int n_clips, int F, int T);
 size_t perceptual_loss_lds_bytes(int T);
 constexpr size_t ADN_LOSS_MAX_LDS = 160 * 1024 - 64;
 constexpr int ADN_LOSS_MAX_T = 6784;
+constexpr int ADN_LOSS_MIN_T = 32;          // loss.py:39-41: the mel transform's reflect padding (31 samples) needs T > 31
 hipError_t launch_perceptual_loss(const float *pred, const float *tgt, int n_clips, int F, int T, float *workspace,
                                   float *out, hipStream_t st);
 

@@ -102,13 +102,23 @@ class WavToSpecDataset(Dataset):
     ``num_workers=4, pin_memory=True``):
 
     * ``ds[i]`` (main process, ``num_workers=0``): device STFT, items come back as host tensors like the reference's
-      datasets.  Inside a DataLoader WORKER process it raises: workers are forked from a parent that has already
-      initialised HIP (``model.to(DEVICE)``, ``train.py:122``) and a forked child cannot use the GPU.
+      datasets.  Inside a DataLoader worker that was FORKED from a parent that has already initialised HIP
+      (``model.to(DEVICE)``, ``train.py:122``, then the default fork start method) it raises: such a child cannot use
+      the GPU.  Workers started with ``multiprocessing_context="spawn"`` (or forked before anything touched the GPU)
+      own a HIP context of their own and work -- at the price of one context per worker.
     * ``ds.loader(clip_samples, batch_size=16, num_workers=4, pin_memory=True, shuffle=True)``: a ``DataLoader`` over
       :meth:`audio_view` whose workers only decode wav files (host I/O) and collate fixed-length audio; the MAIN
       process then runs ONE batched device STFT per batch and yields ``(noisy, clean)`` batches ``(B, 1, H, W)``
       already resident in HBM -- the MI355X-shaped feed (a ``collate_fn`` cannot do this: it runs in the worker).
+      ``subset=`` takes the ``Subset`` objects of ``random_split(ds, ...)`` (``train.py:111-114``) or a list of indices.
     * ``load_batch_to_device(indices)``: the same without a DataLoader.
+
+    ``ds[i]`` transforms the WHOLE file and crops the spectrogram; the loader crops / zero-pads the AUDIO to
+    ``clip_samples`` first.  Both give the same item when ``clip_samples >= min_clip_samples()`` =
+    ``(W - 1) * hop + n_fft // 2``: then every frame inside ``target_size`` sees the same samples (the centre padding is
+    zeros, so a file shorter than ``clip_samples`` agrees as well).  Below that bound a file longer than ``clip_samples``
+    loses samples the last frames would have seen; :meth:`audio_view` / :meth:`loader` refuse it unless
+    ``allow_cut_frames=True``.
 
     No resampling: ``sample_rate`` (if given) is checked against each file.
     """
@@ -146,11 +156,12 @@ class WavToSpecDataset(Dataset):
         return stft_magnitude_fit(a, self.target_size, self.n_fft, self.hop_length, True)
 
     def __getitem__(self, idx):
-        if torch.utils.data.get_worker_info() is not None:
+        if torch.utils.data.get_worker_info() is not None and _forked_from_gpu_parent():
             raise RuntimeError(
                 "WavToSpecDataset computes its spectrograms on the GPU (there is no host STFT) and a DataLoader worker "
-                "process forked from a GPU-initialised parent cannot use HIP.  Use num_workers=0, or let the workers "
-                "decode audio only and transform in the main process: ds.loader(clip_samples, batch_size=..., num_workers=4)")
+                "process forked from a GPU-initialised parent cannot use HIP.  Use num_workers=0, "
+                "multiprocessing_context='spawn', or let the workers decode audio only and transform in the main "
+                "process: ds.loader(clip_samples, batch_size=..., num_workers=4)")
         noisy_path, clean_path = self.pairs[idx]
         noisy, clean = self._audio(noisy_path), self._audio(clean_path)
         if len(noisy) == len(clean):
@@ -165,10 +176,23 @@ class WavToSpecDataset(Dataset):
         return self._spec_batch(noisy), self._spec_batch(clean)
 
     # ---- DataLoader feed: host-only items in the workers, device transform in the main process ---------------
-    def audio_view(self, clip_samples: int):
+    def min_clip_samples(self) -> int:
+        """Samples the frames inside ``target_size`` reach: the last one (index W - 1, centred STFT) ends at
+        ``(W - 1) * hop + n_fft // 2``.  An audio crop at least this long leaves every item equal to ``ds[i]``."""
+        return (self.target_size[1] - 1) * self.hop_length + self.n_fft // 2
+
+    def audio_view(self, clip_samples: int, allow_cut_frames: bool = False):
         """Host-only ``Dataset`` of ``(noisy_audio, clean_audio)`` float32 tensors cropped / zero-padded at the end to
-        ``clip_samples`` -- safe in DataLoader worker processes (wav decoding only, no GPU)."""
-        return _WavAudioView(self, int(clip_samples))
+        ``clip_samples`` -- safe in DataLoader worker processes (wav decoding only, no GPU).  ``clip_samples`` below
+        :meth:`min_clip_samples` would cut samples off frames inside ``target_size`` for longer files (items would
+        differ from ``ds[i]``): refused unless ``allow_cut_frames=True``."""
+        clip_samples = int(clip_samples)
+        if clip_samples < self.min_clip_samples() and not allow_cut_frames:
+            raise ValueError(
+                f"clip_samples={clip_samples} is shorter than the {self.min_clip_samples()} samples the {self.target_size[1]} frames "
+                f"of target_size reach (n_fft {self.n_fft}, hop {self.hop_length}): files longer than clip_samples would give "
+                "other items than ds[i].  Pass a longer clip or allow_cut_frames=True")
+        return _WavAudioView(self, clip_samples)
 
     def to_device_batch(self, host_batch):
         """``(noisy_audio (B, L), clean_audio (B, L))`` host tensors (what a DataLoader over :meth:`audio_view` yields)
@@ -177,13 +201,29 @@ class WavToSpecDataset(Dataset):
         noisy, clean = host_batch
         return self._spec_batch(noisy), self._spec_batch(clean)
 
-    def loader(self, clip_samples: int, **dataloader_kwargs):
+    def loader(self, clip_samples: int, subset=None, allow_cut_frames: bool = False, **dataloader_kwargs):
         """Iterable with the ``DataLoader`` call shape of ``train.py:118-119`` (``batch_size``, ``shuffle``,
-        ``num_workers``, ``pin_memory``, ...) that yields device-resident spectrogram batches."""
-        from torch.utils.data import DataLoader
+        ``num_workers``, ``pin_memory``, ...) that yields device-resident spectrogram batches.  ``subset``: a
+        ``torch.utils.data.Subset`` of this dataset (what ``random_split`` returns, ``train.py:111-114``) or a sequence of
+        indices -- the feed then covers those items only."""
+        from torch.utils.data import DataLoader, Subset
         if "collate_fn" in dataloader_kwargs:
             raise ValueError("loader(): the collate function is fixed (stacked fixed-length audio)")
-        return _DeviceSpecLoader(self, DataLoader(self.audio_view(clip_samples), **dataloader_kwargs))
+        view = self.audio_view(clip_samples, allow_cut_frames)
+        if subset is not None:
+            if isinstance(subset, Subset):
+                if subset.dataset is not self:
+                    raise ValueError("loader(subset=...): the Subset must be a split of this dataset")
+                subset = subset.indices
+            view = Subset(view, [int(i) for i in subset])
+        return _DeviceSpecLoader(self, DataLoader(view, **dataloader_kwargs))
+
+
+def _forked_from_gpu_parent() -> bool:
+    """True in a process forked from a parent that had already initialised the GPU through torch: HIP cannot be used
+    there.  False in spawned workers and in workers forked before anything touched the GPU (both can open a context)."""
+    probe = getattr(torch.cuda, "_is_in_bad_fork", None)
+    return bool(probe()) if probe is not None else True
 
 
 class _DeviceSpecLoader:

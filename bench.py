@@ -118,11 +118,7 @@ def cpu_baseline(sd_np, budget_s: float = 12.0):
 
 def lib_digest() -> str:
     from audiodenoiser_amd import build as B
-    try:
-        with open(B.STAMP) as fh:
-            return fh.read().strip()
-    except OSError:
-        return ""
+    return B.code_digest_of_built_library()
 
 
 def tracked_traffic(kernel_key: str):

@@ -123,7 +123,7 @@ int adn_per_clip_l1(const float *a, const float *b, int n_clips, long elems_per_
  * calls (code/loss.py:6-95; caller code/test.py:118-122).  pred, target: (n_clips,1,F,T) fp32 device tensors;
  * out: (n_clips,4) = {total, stft, mel, l1}.  The reference's batch values are the means over clips (equal clip
  * sizes).  Constants are the reference's: scales (63,16),(32,8),(16,4); mel: sr 8000, n_fft 63, hop 16, 64 mels;
- * weights 0.4/0.4/0.2.  Needs 64 <= T <= ADN_LOSS_MAX_FRAMES (one clip's frequency-mean series, trig tables and mel
+ * weights 0.4/0.4/0.2.  Needs 32 <= T <= ADN_LOSS_MAX_FRAMES (one clip's frequency-mean series, trig tables and mel
  * frames are held in the 160 KiB LDS of one CU; ADN_ERR_INVALID outside, before anything is enqueued) and
  * adn_perceptual_loss_workspace_bytes of device scratch. */
 #define ADN_LOSS_MAX_FRAMES 6784

@@ -12,6 +12,8 @@ import os
 
 import numpy as np
 import pytest
+
+from conftest import load_real_audio_fixture
 import torch
 
 pytestmark = pytest.mark.gpu
@@ -304,8 +306,8 @@ def test_config0_real_audio_stage_by_stage(net, dev, weights_np, golden_dir):
     import oracle
     from audiodenoiser_amd.data_loader import quantize_pad_on_device
     from audiodenoiser_amd.stft import stft_magnitude
-    fx = np.load(os.path.join(golden_dir, "real_audio_17480-2-0-24.npz"))
-    g = np.load(os.path.join(golden_dir, "config0_real_audio.npz"))
+    fx = load_real_audio_fixture(golden_dir)
+    g = load_real_audio_fixture(golden_dir, "config0_real_audio.npz")
     clip = fx["lr_sum_int16"].astype(np.float32) / np.float32(65536.0)
     mag = stft_magnitude(torch.from_numpy(clip).to(dev), 1024, 256, True)
     assert tuple(mag.shape) == (513, 517)
@@ -330,7 +332,7 @@ def test_stft_silence_dc_and_gaps(dev, golden_dir):
     clip with a silent lead-in (frames inside the gap are exactly zero)."""
     import oracle
     from audiodenoiser_amd.stft import stft_magnitude
-    fx = np.load(os.path.join(golden_dir, "real_audio_17480-2-0-24.npz"))
+    fx = load_real_audio_fixture(golden_dir)
     clip = fx["lr_sum_int16"].astype(np.float32) / np.float32(65536.0)
     gapped = clip.copy()
     gapped[:30000] = 0.0
@@ -511,7 +513,7 @@ def test_per_clip_l1(dev):
     assert np.allclose(got, ref, rtol=1e-5)
 
 
-@pytest.mark.parametrize("b,f,t", [(3, 40, 96), (2, 257, 188), (4, 513, 256), (1, 33, 64)])
+@pytest.mark.parametrize("b,f,t", [(3, 40, 96), (2, 257, 188), (4, 513, 256), (1, 33, 64), (2, 40, 32), (3, 24, 48), (2, 16, 63)])
 def test_perceptual_loss_per_clip(dev, b, f, t):
     """Per-clip CombinedPerceptualLoss (loss.py:6-95) against the torch oracle; tolerance 1e-4 relative per term.
     (Mel term: parity unpinned upstream, torchaudio absent — oracle restates its published defaults.)"""
@@ -555,7 +557,7 @@ def test_perceptual_loss_zero_and_errors(dev):
         perceptual_loss_per_clip(x, x[:, :, :32])
     from audiodenoiser_amd._lib import AdnError
     with pytest.raises(AdnError):
-        perceptual_loss_per_clip(x[..., :32].contiguous(), x[..., :32].contiguous())     # T < 64
+        perceptual_loss_per_clip(x[..., :31].contiguous(), x[..., :31].contiguous())     # T < 32: reflect pad 31 needs T > 31
 
 
 # ---------------------------------------------------------------------------------------------- fp16 path
@@ -583,7 +585,8 @@ def test_fp16_path_within_1e2_of_fp32_reference(dev, weights_np, golden_dir):
 
 def test_fp16_path_batch256(dev, weights_np):
     """configs[4] at its stated size, batch 256 x 513x256: finite, clip independent, and two clips within 1e-2 of
-    the fp32 HIP path (itself within 1e-4 of the reference)."""
+    the oracle's fp32 forward (oracle/unet_torch.py: the ATen kernels the reference dispatches to)."""
+    from oracle import unet_torch
     from audiodenoiser_amd.model import UNet
     m = UNet(1, 1)
     m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in weights_np.items()}, strict=True)
@@ -594,10 +597,12 @@ def test_fp16_path_batch256(dev, weights_np):
         y = m(x)
         assert torch.isfinite(y).all()
         assert torch.equal(m(x[100:101].clone())[0], y[100])
-        m.set_compute_dtype("f32")
-        for i in (0, 255):
-            ref = m(x[i:i + 1].clone())
-            assert float((y[i:i + 1] - ref).abs().max() / ref.abs().max()) <= 1e-2
+    sd = unet_torch.to_torch_state(weights_np)
+    for i in (0, 255):
+        ref = unet_torch.unet_forward(sd, x[i:i + 1].cpu()).numpy()
+        assert _rel(y[i:i + 1].cpu().numpy(), ref) <= 1e-2, i
+    m._workspace = None
+    torch.cuda.empty_cache()
 
 
 @pytest.mark.gpu
@@ -631,13 +636,33 @@ def test_wav_to_spec_dataset_matches_oracle(dev, tmp_path):
         WavToSpecDataset(str(tmp_path), sample_rate=16000, device=dev)[0]
     # the DataLoader feed of train.py:118-119: workers decode audio only (host), the main process transforms on the device
     from torch.utils.data import DataLoader
-    loader = ds.loader(8000, batch_size=2, num_workers=2, pin_memory=True)
+    # clip_samples = the 8320 samples the 64 frames reach: every item equals ds[i] although the loader crops / pads the AUDIO
+    # and ds[i] the spectrogram -- files of 8000 and 6000 samples (shorter: zero padded) and of 24000 (longer: cropped)
+    assert ds.min_clip_samples() == 8320
+    with pytest.raises(ValueError, match="8320"):
+        ds.loader(8000, batch_size=2)
+    loader = ds.loader(8320, batch_size=2, num_workers=2, pin_memory=True)
     assert len(loader) == 2
     batches = list(loader)
     assert len(batches) == 2 and all(b[0].is_cuda and b[0].shape == (2, 1, 256, 64) for b in batches)
-    assert torch.equal(batches[0][0], nb) and torch.equal(batches[0][1], cb)         # items 0, 1 are 8000 samples long
+    assert torch.equal(batches[0][0], nb) and torch.equal(batches[0][1], cb)
+    for i in range(4):
+        assert torch.equal(batches[i // 2][0][i % 2].cpu(), ds[i][0]) and torch.equal(batches[i // 2][1][i % 2].cpu(), ds[i][1])
+    # a shorter crop is allowed on request; the 24000-sample file then differs from ds[3] in the frames that reach past it
+    cut = list(ds.loader(8000, allow_cut_frames=True, batch_size=4))[0][0]
+    assert torch.equal(cut[0].cpu(), ds[0][0]) and not torch.equal(cut[3].cpu(), ds[3][0])
+    assert torch.equal(cut[3, :, :, :60].cpu(), ds[3][0][:, :, :60])
+    # train.py:111-119 as written: random_split, then a loader per split
+    from torch.utils.data import random_split
+    tr_split, va_split = random_split(ds, [3, 1], generator=torch.Generator().manual_seed(1))
+    vb = list(ds.loader(8320, subset=va_split, batch_size=2))
+    assert len(vb) == 1 and torch.equal(vb[0][0][0].cpu(), ds[va_split.indices[0]][0])
+    # DataLoader(ds, num_workers > 0) itself: a worker forked from this GPU-initialised process cannot use HIP -> clear error;
+    # a spawned worker opens its own context and works
     with pytest.raises(RuntimeError, match="DataLoader worker"):
         next(iter(DataLoader(ds, batch_size=2, num_workers=1)))
+    sp = next(iter(DataLoader(ds, batch_size=2, num_workers=1, multiprocessing_context="spawn")))
+    assert torch.equal(sp[0][0], ds[0][0]) and torch.equal(sp[1][1], ds[1][1])
 
 
 @pytest.mark.gpu

@@ -326,9 +326,19 @@ def test_wav_dataset_worker_guard_and_audio_view(tmp_path):
         write_wav(str(tmp_path / f"clean_{i}.wav"), rng.uniform(-1, 1, n).astype(np.float32), 8000, "FLOAT")
         write_wav(str(tmp_path / f"noisy_{i}.wav"), rng.uniform(-1, 1, n).astype(np.float32), 8000, "FLOAT")
     ds = WavToSpecDataset(str(tmp_path), sample_rate=8000)
-    with pytest.raises(RuntimeError, match="DataLoader worker"):
-        next(iter(DataLoader(ds, batch_size=2, num_workers=1)))
-    view = ds.audio_view(1000)
+    if torch.cuda.is_available():                          # (forked from a GPU-initialised parent: covered by the -m gpu test)
+        torch.zeros(1, device="cuda")
+        with pytest.raises(RuntimeError, match="DataLoader worker"):
+            next(iter(DataLoader(ds, batch_size=2, num_workers=1)))
+    # ds[i] transforms the whole file and crops the spectrogram, the loader crops the audio first: the two agree when the crop
+    # keeps every sample the frames inside target_size reach -- (64 - 1) * 128 + 256 = 8320 for the defaults
+    assert ds.min_clip_samples() == 8320
+    with pytest.raises(ValueError, match="8320"):
+        ds.audio_view(1000)
+    with pytest.raises(ValueError, match="allow_cut_frames"):
+        ds.loader(8000, batch_size=2)
+    assert len(ds.audio_view(8320)) == 4
+    view = ds.audio_view(1000, allow_cut_frames=True)
     assert len(view) == 4
     batches = list(DataLoader(view, batch_size=2, num_workers=2))
     assert len(batches) == 2
@@ -340,10 +350,21 @@ def test_wav_dataset_worker_guard_and_audio_view(tmp_path):
     from audiodenoiser_amd.wav import read_wav
     assert np.array_equal(n1.numpy(), read_wav(str(tmp_path / "noisy_1.wav"))[0][:1000])
     with pytest.raises(ValueError):
-        ds.audio_view(100)
+        ds.audio_view(100, allow_cut_frames=True)
     with pytest.raises(ValueError):
-        ds.loader(1000, collate_fn=lambda b: b)
-    assert len(ds.loader(1000, batch_size=3, num_workers=2)) == 2
+        ds.loader(1000, allow_cut_frames=True, collate_fn=lambda b: b)
+    assert len(ds.loader(1000, allow_cut_frames=True, batch_size=3, num_workers=2)) == 2
+    # train.py:111-114 splits the dataset with random_split before it builds the loaders: the Subset objects feed loader()
+    from torch.utils.data import random_split
+    train_ds, val_ds = random_split(ds, [3, 1], generator=torch.Generator().manual_seed(0))
+    lt, lv = ds.loader(8320, subset=train_ds, batch_size=2), ds.loader(8320, subset=val_ds, batch_size=2)
+    assert len(lt) == 2 and len(lv) == 1
+    got = [int(i) for i in lt.host_loader.dataset.indices] + [int(i) for i in lv.host_loader.dataset.indices]
+    assert sorted(got) == [0, 1, 2, 3] and got[:3] == list(train_ds.indices)
+    assert len(ds.loader(8320, subset=[2, 0], batch_size=1)) == 2
+    other = WavToSpecDataset(str(tmp_path), sample_rate=8000)
+    with pytest.raises(ValueError, match="split of this dataset"):
+        other.loader(8320, subset=train_ds)
 
 
 def test_cpu_tensors_without_a_device_raise_instead_of_computing(weights_np):
@@ -374,7 +395,10 @@ def test_perceptual_loss_frame_limit_is_reported_before_any_launch():
     p = ctypes.cast(buf, ctypes.c_void_p)
     assert L.adn_perceptual_loss(p, p, 1, 64, tmax + 1, p, 1 << 40, p, None) == 1     # rejected on the host
     assert b"6784" in L.adn_last_error()
-    assert L.adn_perceptual_loss(p, p, 1, 64, 63, p, 1 << 40, p, None) == 1
+    assert L.adn_perceptual_loss(p, p, 1, 64, 31, p, 1 << 40, p, None) == 1           # reflect pad of 31 needs T >= 32 (loss.py:39-41)
+    assert b"32 <= T" in L.adn_last_error()
+    assert L.adn_perceptual_loss_workspace_bytes(1, 64, 31, ctypes.byref(need)) == 1
+    assert L.adn_perceptual_loss_workspace_bytes(1, 64, 32, ctypes.byref(need)) == 0 and need.value == 2 * (2 * 32 + 1) * 4
 
 
 def test_compat_modules_resolve_reference_import_names():
@@ -510,7 +534,12 @@ def test_library_digest_identifies_code_not_comments(tmp_path, monkeypatch):
     """profiles/pmc_traffic.json is tied to a build by the digest of its sources; comments and whitespace do not count."""
     from audiodenoiser_amd import build as B
     src = 'int a = 1; // note\n/* block\n comment */ const char *s = "// kept /* kept */"; char c = \'"\';  // tail \\\ncontinued\nint b = 2;\n'
-    assert B._strip_comments(src) == 'int a = 1; const char *s = "// kept /* kept */"; char c = \'"\'; int b = 2;'
+    assert B._strip_comments(src) == 'int a = 1; const char *s = "// kept /* kept */"; char c = \'"\'; int b = 2; '
+    # spacing inside a literal is code, and so is the newline that ends a preprocessor directive
+    assert B._strip_comments('f("a  b");') != B._strip_comments('f("a b");')
+    assert B._strip_comments("#define X 1\nint y;\n") != B._strip_comments("#define X 1 int y;\n")
+    assert B._strip_comments("#define X(a) \\\n    ((a) + 1)\nint y;\n") == "#define X(a) ((a) + 1)\nint y; "
+    assert B._strip_comments("int   a ;\n\n  int b;") == B._strip_comments("int a ; int b;")
     csrc = tmp_path / "csrc"
     inc = tmp_path / "include"
     csrc.mkdir()
@@ -522,5 +551,8 @@ def test_library_digest_identifies_code_not_comments(tmp_path, monkeypatch):
     d0 = B._digest()
     (csrc / "k.hip").write_text("// reworded comment\n\n__global__ void k(float *p)   { p[0] = 1.f; }   /* same code */\n")
     assert B._digest() == d0
+    r0 = B._raw_digest()
+    (csrc / "k.hip").write_text("// reworded again\n\n__global__ void k(float *p)   { p[0] = 1.f; }   /* same code */\n")
+    assert B._digest() == d0 and B._raw_digest() != r0        # any edit rebuilds; only code edits orphan the PMC profile
     (csrc / "k.hip").write_text("__global__ void k(float *p) { p[0] = 2.f; }\n")
     assert B._digest() != d0

@@ -7,6 +7,8 @@ import os
 
 import numpy as np
 import pytest
+
+from conftest import load_real_audio_fixture
 import torch
 
 import oracle
@@ -91,7 +93,7 @@ def test_loader_quantize_pad_matches_reference(golden_dir):
 
 
 def _real_clip(golden_dir):
-    fx = np.load(os.path.join(golden_dir, "real_audio_17480-2-0-24.npz"))
+    fx = load_real_audio_fixture(golden_dir)
     assert int(fx["sample_rate"]) == 44100 and fx["lr_sum_int16"].shape == (132300,)
     return fx["lr_sum_int16"].astype(np.float32) / np.float32(65536.0)      # mean(L, R) / 32768, exact in fp32
 
@@ -101,7 +103,7 @@ def test_config0_real_audio_oracle_chain_matches_reference_golden(golden_dir, we
     -> loader rule -> forward.  The loader and forward stages are pinned by config0_real_audio.npz, which the
     reference's own data_loader.py + model.py produced from the same STFT (tools/make_golden.py --only config0); the
     STFT stage is parity unpinned (librosa absent) and cross-checked in tests/test_stft_oracle.py."""
-    g = np.load(os.path.join(golden_dir, "config0_real_audio.npz"))
+    g = load_real_audio_fixture(golden_dir, "config0_real_audio.npz")
     clip = _real_clip(golden_dir)
     assert 0.1 < np.abs(clip).max() < 0.2 and clip.std() < 0.02            # quiet real recording, 21 dB crest factor
     mag = oracle.stft_mag(clip, 1024, 256, True)

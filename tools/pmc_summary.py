@@ -150,7 +150,7 @@ def main():
         digest = ""
         try:
             with open(os.path.join(ROOT, "audiodenoiser_amd", "_lib", "libadn.sha256")) as fh:
-                digest = fh.read().strip()
+                digest = fh.readline().strip()        # first line = code digest (audiodenoiser_amd/build.py)
         except OSError:
             pass
         rec = {"lib_digest": digest,
