@@ -3,6 +3,7 @@ or built, every entry point raises."""
 from __future__ import annotations
 
 import ctypes
+import os
 import threading
 
 from . import build as _build
@@ -23,8 +24,9 @@ def load() -> ctypes.CDLL:
     with _lock:
         if _lib is not None:
             return _lib
+        variant = os.environ.get("ADN_LIBADN_PATH")       # variant sweeps of tools/ (build.build_variant); unset in production
         try:
-            path = _build.build()
+            path = variant if variant else _build.build()
         except Exception as exc:  # noqa: BLE001 - re-raised with context
             raise AdnError(f"libadn.so (MI355X HIP kernels) is missing and could not be built: {exc}") from exc
         # PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so, soname libamdhip64.so.7).  It must be

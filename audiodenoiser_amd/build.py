@@ -188,5 +188,32 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_variant(name: str, defines, experiments: bool = True) -> str:
+    """Cross-compile a build-time VARIANT of the library (extra -D switches, by default with the experiment switches
+    compiled in) to ``_lib/variants/libadn_<name>.so`` without touching the production library.  Variant sweeps are
+    compiled in the build container and shipped to the GPU box with the tree; a process picks one with
+    ``ADN_LIBADN_PATH`` (see ``_lib.load``).  Tools only: nothing in the product path sets that variable."""
+    hipcc = hipcc_path()
+    if hipcc is None:
+        raise RuntimeError("hipcc not found")
+    vdir = os.path.join(LIBDIR, "variants")
+    os.makedirs(vdir, exist_ok=True)
+    dst = os.path.join(vdir, f"libadn_{name}.so")
+    flags = (["-DADN_EXPERIMENTS"] if experiments else []) + list(defines)
+    with tempfile.TemporaryDirectory(prefix="adn_variant_") as objdir:
+        def compile_one(src):
+            obj = os.path.join(objdir, os.path.basename(src) + ".o")
+            subprocess.run([hipcc, f"--offload-arch={ARCH}"] + COMMON_FLAGS + [f"-I{INCLUDE}"] + flags
+                           + FILE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj], check=True)
+            return obj
+        with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, (os.cpu_count() or 2) // 2)) as pool:
+            objs = list(pool.map(compile_one, _sources()))
+        subprocess.run([hipcc, f"--offload-arch={ARCH}", "-fPIC", "-shared", "-o", dst] + objs, check=True)
+    return dst
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if len(sys.argv) > 2 and sys.argv[1] == "--variant":          # python -m audiodenoiser_amd.build --variant NAME [-D...]
+        print(build_variant(sys.argv[2], [a for a in sys.argv[3:] if a != "--production"], "--production" not in sys.argv))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

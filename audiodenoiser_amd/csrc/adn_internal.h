@@ -49,6 +49,16 @@ struct ConvSrc {
     int offY, offX;
 };
 
+// Division of a wave-uniform index by a launch constant without the ~25-instruction software divide: q = mulhi(n, ceil(2^32 / d)),
+// exact while n * d < 2^32 (the launcher checks its grid against that); d == 1 passes n through.
+struct FastDiv {
+    unsigned d, m;
+};
+inline FastDiv make_fastdiv(unsigned d) { return FastDiv{d, d > 1 ? (unsigned)((0x100000000ull + d - 1) / d) : 0u}; }
+#ifdef __HIPCC__
+__device__ __forceinline__ int fastdiv(int n, FastDiv f) { return f.d == 1 ? n : (int)__umulhi((unsigned)n, f.m); }
+#endif
+
 // Arguments of the matrix-core convolution kernels (3x3 convolution or 2x2-stride-2 transposed convolution).
 struct ConvArgs {
     ConvSrc s0, s1;        // channels [0, s0.C) come from s0, [s0.C, s0.C + s1.C) from s1 (virtual concat)
@@ -62,6 +72,7 @@ struct ConvArgs {
     int Cout;              // output channels of the layer (GEMM columns = Cout, or 4*Cout for convT)
     int tilesY, tilesX, nct;
     int pair;              // wino4_conv_f32 only: 1 = a workgroup tile holds two clips side by side (images <= 16 px wide)
+    FastDiv fdGc, fdNcg, fdTx, fdTy;   // wino4_conv_f32 only: the divisors of its tile decode (fdGc.d == 0: plain division)
     int ablate;            // timing experiments only (ADN_WINO_ABLATE); 0 in production
     const float *zeros;    // >= 16 bytes of zeros in device memory (source of padding lanes of the LDS-DMA copy)
     void *dbg;             // diagnostic stamp buffer (ADN_WINO_STAMP); nullptr in production

@@ -377,7 +377,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void stft_wave_kernel(const float *__
                                                              float *__restrict__ out, int ablate_arg, const StftOut o)
 {
 #ifdef ADN_EXPERIMENTS
-    const int ablate = ablate_arg;              // timing experiments (ADN_STFT_ABLATE): skip loads (1) / stores (2)
+    const int ablate = ablate_arg;              // timing experiments (ADN_STFT_ABLATE): skip loads (1) / stores (2) / FFT passes (4)
 #else
     constexpr int ablate = 0;
     (void)ablate_arg;
@@ -493,6 +493,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void stft_wave_kernel(const float *__
             }
         }
 
+        if (!(ablate & 4)) {                   // (4: timing experiment -- the three FFT passes skipped, everything else kept)
         // pass 1: radix 8, P = 1
         vdft<8>(v);
 #pragma unroll
@@ -500,6 +501,10 @@ __global__ __launch_bounds__(NW * 64, WPE) void stft_wave_kernel(const float *__
         wave_lds_fence();
         wave_pass<M, R2, 8, 1, (R3 > 1 ? 2 : 3)>(sc, tw2, t, v);
         if constexpr (R3 > 1) wave_pass<M, R3, 8 * R2, 2, 3>(sc, tw3, t, v);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) asm volatile("" ::"v"(v[q]));
+        }
 
         // ---- real-FFT post-processing + magnitude into the [bin][frame] image ----
         float *mg = s_mag + fcol;
@@ -574,6 +579,178 @@ __global__ __launch_bounds__(NW * 64, WPE) void stft_wave_kernel(const float *__
     for (int it = 0; it < n_seq; ++it) frame(it);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused STFT -> network input (adn_stft_mag_fit): PERSISTENT workgroups on whole output lines.
+//
+// The plain layout (bins x n_frames, n_frames odd) gives no frame group whole cache lines, which is what rules persistence
+// out for stft_wave_kernel (two halves of a line must reach the L2 together).  The fitted window does not have that problem:
+// rows are W floats apart (1024 bytes for 513x256), so a group of 32 frames is exactly one 128-byte line per bin row.  Here
+//   * a workgroup walks a contiguous run of (clip, 32-frame group) items: the constant set-up (table copy, two barriers, 26
+//     LDS reads per lane), the launch and the first frame's unprefetched HBM round trip are paid once per workgroup instead
+//     of once per 16 frames, and the next group's first frames are prefetched under the last FFTs of the current one;
+//   * the values leave as fp16 round trips anyway (data_loader.py:41-42), so the [bin][frame] image holds HALFS: 32 frames
+//     fit the 33 KB the 16-frame fp32 image took, three workgroups per CU as before;
+//   * a lane stores 16 bytes (4 frames of one row), 8 lanes one whole line: 4x fewer store instructions.
+// Image: row k = 32 halfs (64 bytes); the 8-byte piece p (frames 4p .. 4p+3) of row k sits at piece p ^ ((k >> 1) & 7), so
+// that the transposed writes of a frame (64 bins, one half each) spread over 16 banks (2-way, free for 2-byte writes)
+// while the store phase's ds_read_b64 of 4 rows x 8 pieces per 32-lane group stays conflict-free.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int fit_col(int k, int c) { return ((((c >> 2) ^ (k >> 1)) & 7) << 2) | (c & 3); }
+
+template <int M, int NW, int WPE>
+__global__ __launch_bounds__(NW * 64, WPE) void stft_fit_kernel(const float *__restrict__ audio, long L, int hop, int pad,
+                                                               int nfc, int gpc, int total, const float *__restrict__ tables,
+                                                               float *__restrict__ out, const StftOut o)
+{
+    constexpr int N = 2 * M, TPF = M / 8, NT = NW * 64, FPB = 32;
+    constexpr int SLOTS = NT / TPF, FPS = FPB / SLOTS;       // frames per slot and group, processed in sequence
+    constexpr int SCSZ = exch_size<M>();
+    constexpr int R2 = WavePlan<M>::R2, R3 = WavePlan<M>::R3;
+    constexpr int TBL = N + 2 * M + (M + 2);
+    static_assert(TPF <= 64 && FPB % SLOTS == 0 && FPS >= 1 && M >= 128, "bad STFT tiling");
+    static_assert(TBL * 4 <= (M + 1) * FPB * 2, "table must fit the magnitude image");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    _Float16 *s_img = reinterpret_cast<_Float16 *>(smem);                                   // (M+1) x 32 halfs
+    v2f *s_sc = reinterpret_cast<v2f *>(smem + (((M + 1) * FPB / 2 + 3) & ~3));
+
+    const int tid = threadIdx.x;
+    const int slot = (TPF == 64) ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid / TPF;
+    const int t = tid - slot * TPF;
+    // contiguous run of items: consecutive groups of a clip share 3/4 of a frame of audio and write neighbouring lines
+    const int it0 = (int)((long)blockIdx.x * total / gridDim.x), it1 = (int)((long)(blockIdx.x + 1) * total / gridDim.x);
+    if (it0 >= it1) return;
+    v2f *sc = s_sc + slot * SCSZ;
+    const int Li = (int)L;
+
+    // 8-byte loads need an even sample offset from an 8-byte aligned clip (clips of odd length alternate)
+    auto load_frame = [&](const float *aud, int fidx, v2f *dst) {
+        const int fstart = fidx * hop - pad;
+        const float *ap = aud + fstart + 2 * t;
+        if (fstart >= 0 && fstart + N <= Li && !(reinterpret_cast<uintptr_t>(aud + fstart) & 7)) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) dst[u] = *reinterpret_cast<const v2f *>(ap + 2 * u * TPF);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int s = fstart + 2 * (t + u * TPF);
+                dst[u].x = (s >= 0 && s < Li) ? ap[2 * u * TPF] : 0.f;
+                dst[u].y = (s + 1 >= 0 && s + 1 < Li) ? ap[2 * u * TPF + 1] : 0.f;
+            }
+        }
+    };
+
+    int clip = it0 / gpc, g = it0 - clip * gpc, fi = 0;
+    const float *aud = audio + (long)clip * L;
+    v2f nx[8];
+    load_frame(aud, g * FPB + slot * FPS, nx);            // requested before the constant set-up (overlaps it)
+
+    {
+        float *tb = smem;
+        for (int i = tid * 4; i < TBL; i += NT * 4) {
+            if (i + 4 <= TBL) *reinterpret_cast<f4 *>(tb + i) = *reinterpret_cast<const f4 *>(tables + i);
+            else
+                for (int j = i; j < TBL; ++j) tb[j] = tables[j];
+        }
+        __syncthreads();
+    }
+    v2f win[8], tw2[(R2 - 1) * (8 / R2)], tw3[R3 > 1 ? (R3 - 1) * (8 / R3) : 1], twp[4];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) win[u] = 0.5f * *reinterpret_cast<const v2f *>(smem + 2 * (t + u * TPF));
+    load_pass_twiddles<M, R2, 8>(smem, t, tw2);
+    if constexpr (R3 > 1) load_pass_twiddles<M, R3, 8 * R2>(smem, t, tw3);
+    {
+        const v2f *g2 = reinterpret_cast<const v2f *>(smem + N + 2 * M);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) twp[b] = g2[t + b * TPF];
+    }
+    __syncthreads();
+
+    const bool vec_ok = ((reinterpret_cast<uintptr_t>(out) & 15) == 0) && !(o.row_stride & 3) && !(o.clip_stride & 3);
+    const int n_seq = (it1 - it0) * FPS;
+#pragma unroll 1
+    for (int it = 0; it < n_seq; ++it) {
+        const int fcol = slot * FPS + fi;
+        v2f v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = nx[u] * win[u];
+        // next frame of this slot: the next column, or the first column of the next item (possibly the next clip)
+        int fn = fi + 1, gn = g, cn = clip;
+        if (fn == FPS) {
+            fn = 0;
+            if (++gn == gpc) { gn = 0; ++cn; }
+        }
+        if (it + 1 < n_seq) {
+            const float *an = audio + (long)cn * L;
+            const int fnx = gn * FPB + slot * FPS + fn;
+            const int fs = fnx * hop - pad;
+            if (hop * 4 == N && fn != 0 && fs >= 0 && fs + N <= Li && !(reinterpret_cast<uintptr_t>(an + fs) & 7)) {
+#pragma unroll
+                for (int u = 0; u < 6; ++u) nx[u] = nx[u + 2];
+                const float *ap = an + fs + 2 * t;
+                nx[6] = *reinterpret_cast<const v2f *>(ap + 2 * 6 * TPF);
+                nx[7] = *reinterpret_cast<const v2f *>(ap + 2 * 7 * TPF);
+            } else {
+                load_frame(an, fnx, nx);
+            }
+        }
+
+        vdft<8>(v);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) ADN_XWR(sc + xidx<M, 1>(8 * t + q), v[q]);
+        wave_lds_fence();
+        wave_pass<M, R2, 8, 1, (R3 > 1 ? 2 : 3)>(sc, tw2, t, v);
+        if constexpr (R3 > 1) wave_pass<M, R3, 8 * R2, 2, 3>(sc, tw3, t, v);
+
+        v2f pa[4], pb[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int k = t + b * TPF;
+            pa[b] = ADN_XRD(sc + xidx<M, 3>(k));
+            pb[b] = ADN_XRD(sc + xidx<M, 3>((M - k) & (M - 1)));
+        }
+        const v2f zh = 2.0f * ADN_XRD(sc + xidx<M, 3>(M / 2));
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int k = t + b * TPF;
+            const v2f A = pa[b], Bc = pb[b];
+            const v2f ev = vadd_conj(A, Bc), d = vsub_conj(A, Bc);
+            const v2f wo = vmul_negi(twp[b], d);
+            const v2f xa = ev + wo, xb = ev - wo;
+            s_img[k * FPB + fit_col(k, fcol)] = (_Float16)__builtin_amdgcn_sqrtf(xa.x * xa.x + xa.y * xa.y);
+            s_img[(M - k) * FPB + fit_col(M - k, fcol)] = (_Float16)__builtin_amdgcn_sqrtf(xb.x * xb.x + xb.y * xb.y);
+        }
+        if (t == 0) s_img[(M / 2) * FPB + fit_col(M / 2, fcol)] = (_Float16)__builtin_amdgcn_sqrtf(zh.x * zh.x + zh.y * zh.y);
+        wave_lds_fence();
+
+        if (fi == FPS - 1) {
+            // ---- group complete: 8 lanes per row, 16 bytes (4 frames) per lane -> whole 128-byte lines ----
+            __syncthreads();
+            const int p = tid & 7, f0 = g * FPB + 4 * p;
+            float *ob = out + (long)clip * o.clip_stride + f0;
+            if (f0 < nfc) {
+#pragma unroll 4
+                for (int row = tid >> 3; row < o.rows; row += NT / 8) {
+                    const h4 hv = *reinterpret_cast<const h4 *>(s_img + row * FPB + (((p ^ (row >> 1)) & 7) << 2));
+                    const f4 fv = {(float)hv.x, (float)hv.y, (float)hv.z, (float)hv.w};
+                    float *op = ob + (long)row * o.row_stride;
+                    if (vec_ok && f0 + 4 <= nfc) {
+                        *reinterpret_cast<f4 *>(op) = fv;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (f0 + j < nfc) op[j] = fv[j];
+                    }
+                }
+            }
+            __syncthreads();   // image is rewritten by the next group
+        }
+        fi = fn;
+        g = gn;
+        clip = cn;
+    }
+}
+
 inline int stft_ablate()
 {
 #ifdef ADN_EXPERIMENTS
@@ -605,6 +782,42 @@ hipError_t launch_wave(const float *audio, int n_clips, long L, int hop, int pad
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(NW * 64), lds, st, audio, L, hop, pad, n_frames, (int)groups,
                        gpb, (int)bpc, tables, out, stft_ablate(), o);
+    return hipGetLastError();
+}
+
+template <int M, int NW, int WPE = 3>
+hipError_t launch_fit(const float *audio, int n_clips, long L, int hop, int pad, long n_frames, const float *tables,
+                      float *out, const StftOut &o, hipStream_t st)
+{
+    constexpr int TPF = M / 8, SLOTS = NW * 64 / TPF, FPB = 32;
+    const long gpc = (n_frames + FPB - 1) / FPB;
+    const long total = gpc * n_clips;
+    if (total <= 0 || total > 0x7fffffffL || n_frames > 0x7fffffffL) return hipErrorInvalidValue;
+    const size_t lds = (size_t)((((M + 1) * FPB / 2 + 3) & ~3) + 2 * SLOTS * exch_size<M>()) * sizeof(float);
+    auto kern = stft_fit_kernel<M, NW, WPE>;
+    // persistent grid: exactly as many workgroups as the chip holds at once (asked of the runtime for THIS kernel and LDS size)
+    struct Res { int dev = -1, wgs = 0; };
+    static thread_local Res cache;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (cache.dev != dev) {
+        if (lds > 64 * 1024) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        int per_cu = 0, cus = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, NW * 64, lds);
+        if (e != hipSuccess) return e;
+        e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess) return e;
+        if (per_cu < 1 || cus < 1) return hipErrorInvalidValue;
+        cache.dev = dev;
+        cache.wgs = per_cu * cus;
+    }
+    const long nwg = total < cache.wgs ? total : cache.wgs;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(NW * 64), lds, st, audio, L, hop, pad, (int)n_frames, (int)gpc,
+                       (int)total, tables, out, o);
     return hipGetLastError();
 }
 
@@ -696,6 +909,19 @@ hipError_t launch_stft_mag(const float *audio, int n_clips, long L, int n_fft, i
     constexpr int variant = -1;
     constexpr int gpb = 1;                                // frame groups per workgroup (1 measured best: no in-loop barriers)
 #endif
+#ifdef ADN_EXPERIMENTS
+    static const bool fit_persistent = []() { const char *e = std::getenv("ADN_STFT_FIT_PERSISTENT"); return !e || std::atoi(e) != 0; }();
+#else
+    constexpr bool fit_persistent = true;
+#endif
+    if (quantize && fit_persistent && variant != 0) {          // adn_stft_mag_fit: persistent whole-line kernel (above)
+        switch (n_fft) {
+            case 256: return launch_fit<128, 4>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st);
+            case 512: return launch_fit<256, 4>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st);
+            case 1024: return launch_fit<512, 4>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st);
+            default: break;
+        }
+    }
     if (variant != 0) {
         switch (n_fft) {
             case 64: return launch_wave<32, 1, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st, gpb);

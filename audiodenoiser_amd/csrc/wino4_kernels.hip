@@ -54,6 +54,29 @@ constexpr int KC = 8;                        // input channels per chunk
 #ifndef W4_TPIN                               // 1: the whole input transform of a pass in front of its first MFMA (below)
 #define W4_TPIN 1
 #endif
+// W4_SWAP: accumulators cout-major (MFMA operands swapped: a lane holds 4 consecutive couts of one tile instead of one cout of
+// 4 tiles): 0 = never, 1 = every variant, 2 = only the fused-1x1 variant.  Measured per batch-64 step (profiles/r03_wino4_variants.txt):
+// the fused-1x1 layer gains 3.3 % (a lane adds its 4 couts in registers: 16 instead of 64 LDS writes in the dot), the plain and
+// pooling variants LOSE 2-4 % with the 16-byte stores this layout allows (same K loop instruction mix; tools/ubench/
+// mfma_operands.hip shows no operand-order effect in the MFMAs themselves) -> 2.
+#ifndef W4_SWAP
+#define W4_SWAP 2
+#endif
+#ifndef W4_EARLY_U                            // 1: a pass's first B fragment is requested before its input transform, not behind it (-0.2 %)
+#define W4_EARLY_U 1
+#endif
+#ifndef W4_PRE_U1                             // 1: the second pass's first B fragment is requested before the barrier between the passes
+#define W4_PRE_U1 0                           //    (measured +0.4 %: not used)
+#endif
+#ifndef W4_FASTDIV                            // 1: tile decode by multiply-high with launch constants instead of seven software divisions
+#define W4_FASTDIV 1
+#endif
+#ifndef W4_BIAS_ACC                           // 1: the bias rides in the accumulator of transform-domain position (1, 1) (below): -0.8 %
+#define W4_BIAS_ACC 1
+#endif
+#if W4_SWAP && !W4_BIAS_ACC
+#error "W4_SWAP needs W4_BIAS_ACC (its epilogue has no bias add)"
+#endif
 #ifndef W4_PR                                 // (tools/wino4_variants.sh sweeps these two: 5 from group 0 measured best, 35.17 ms per step;
 #define W4_PR 5                               //  4 / 6 / 10 per group 35.36 / 35.27 / 35.5, 5 from group 3 35.74)
 #define W4_PR0 0
@@ -194,6 +217,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // spills: the pooling and fused-1x1 variants run 4-6 % faster); the plain variant is faster (up to 6 %) in the other
     // form, which spills 7 registers once per workgroup.
     constexpr bool LEAN = EPI != CONV3X3_RELU;
+    constexpr bool SWP = W4_SWAP == 1 || (W4_SWAP == 2 && EPI == CONV3X3_RELU_DOT);      // cout-major accumulators (W4_SWAP above)
 
 #ifdef ADN_EXPERIMENTS
     // workgroup timeline (ADN_W4_TIMELINE, p.dbg != nullptr): clock at entry / first chunk ready / loop done / stores issued /
@@ -217,17 +241,33 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // a supertile of gc cout tiles x gp pixel tiles, so every U slab and every halo is an L2 hit for all but one of them
     // (gc = as many cout tiles as there are, up to all 32 slots: measured 0.5 % faster than capping gc at 8)
     const int lid = xcd_remap4(blockIdx.x, gridDim.x);
-    const int gc = p.nct < SUP ? p.nct : SUP, gp = SUP / gc;
-    const int ncg = p.nct / gc;
-    const int sg = lid / SUP, wl = lid - sg * SUP;
-    const int ct = (sg % ncg) * gc + wl % gc;
-    int pt = (sg / ncg) * gp + wl / gc;
     const int pair = p.pair;                              // 1: two clips side by side in the tile (see RSL above)
-    if (pt >= ((p.N + pair) >> pair) * p.tilesY * p.tilesX) return;   // padding of the last supertile (whole workgroup exits)
-    const int tx = pt % p.tilesX;
-    pt /= p.tilesX;
-    const int ty = pt % p.tilesY;
-    const int n = (pt / p.tilesY) << pair;               // (first) clip of the tile
+    int ct, pt, tx, ty, n;
+    if (W4_FASTDIV && p.fdGc.d) {
+        // the seven divisions of the decode cost ~1000 clocks of every workgroup's start as software divides; the divisors are
+        // launch constants, so the launcher passes their reciprocals (FastDiv, adn_internal.h)
+        const int gc = p.fdGc.d, sg = lid >> 5, wl = lid & (SUP - 1);
+        const int wq = fastdiv(wl, p.fdGc), sq = fastdiv(sg, p.fdNcg);
+        ct = (sg - sq * (int)p.fdNcg.d) * gc + (wl - wq * gc);
+        pt = sq * (SUP / gc) + wq;
+        if (pt >= ((p.N + pair) >> pair) * p.tilesY * p.tilesX) return;   // padding of the last supertile (whole workgroup exits)
+        const int py = fastdiv(pt, p.fdTx);
+        tx = pt - py * p.tilesX;
+        const int pn = fastdiv(py, p.fdTy);
+        ty = py - pn * p.tilesY;
+        n = pn << pair;
+    } else {
+        const int gc = p.nct < SUP ? p.nct : SUP, gp = SUP / gc;
+        const int ncg = p.nct / gc;
+        const int sg = lid / SUP, wl = lid - sg * SUP;
+        ct = (sg % ncg) * gc + wl % gc;
+        pt = (sg / ncg) * gp + wl / gc;
+        if (pt >= ((p.N + pair) >> pair) * p.tilesY * p.tilesX) return;   // padding of the last supertile (whole workgroup exits)
+        tx = pt % p.tilesX;
+        pt /= p.tilesX;
+        ty = pt % p.tilesY;
+        n = (pt / p.tilesY) << pair;               // (first) clip of the tile
+    }
     const int gy0 = ty * REG - 1, gx0 = tx * REG - 1;
 
 #ifdef ADN_EXPERIMENTS
@@ -318,13 +358,30 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
 
     // after the epilogue's exchange this wave finishes cout block jh of its tile block
-    const float bias_pre = LEAN ? 0.f : p.bias[ct * 32 + 16 * jh + ti];
+    const float bias_pre = (LEAN || W4_BIAS_ACC) ? 0.f : p.bias[ct * 32 + 16 * jh + ti];
 
     f32x4 acc[2][18];                                  // [cout block: 0 = the one this wave finishes (jh), 1 = the partner's][position]
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int s = 0; s < 18; ++s) acc[j][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if W4_BIAS_ACC
+    // The bias rides in the accumulator of transform-domain position (1, 1): A^T has a column of ones there, so A^T M A adds
+    // M(1,1) to all 16 outputs of a tile.  That position (p = 3*1 + 1 = 4) belongs to the waves of column half 0, for both
+    // cout blocks (their sums for block 1 go to the partner wave in the epilogue): no bias load or add in the epilogue.
+    if (jh == 0) {
+        if constexpr (SWP) {
+            const int q4 = 4 * (lane_id() >> 4);        // register i = cout 4q + i
+            acc[0][4] = *reinterpret_cast<const f32x4 *>(p.bias + ct * 32 + q4);
+            acc[1][4] = *reinterpret_cast<const f32x4 *>(p.bias + ct * 32 + 16 + q4);
+        } else {
+            const int c16 = lane_id() & 15;             // every register of a lane is cout c16 (of four tiles)
+            const float b0 = p.bias[ct * 32 + c16], b1 = p.bias[ct * 32 + 16 + c16];
+            acc[0][4] = f32x4{b0, b0, b0, b0};
+            acc[1][4] = f32x4{b1, b1, b1, b1};
+        }
+    }
+#endif
 
     // patch reads: lane (ti, q) reads channels 2q, 2q+1 (one ds_read_b64) of pixel columns jh .. jh+4 of the 6 patch rows
     // of tile (ti >> 2, ti & 3)
@@ -344,6 +401,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     tlb = __builtin_amdgcn_s_memtime();                 // first copies issued
 #endif
     if (!(ABL & 8192)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // 8192: timing experiment, first chunk not awaited
+#if W4_BIAS_ACC
+    // the bias loads above are consumed HERE (everything has landed): hipcc must not place their wait inside the K loop,
+    // where a vmcnt of its own would drain the copies in flight
+    asm volatile("" : "+v"(acc[0][4]), "+v"(acc[1][4]));
+#endif
 #ifdef ADN_EXPERIMENTS
     tlc = __builtin_amdgcn_s_memtime();                 // this wave's copies landed
 #endif
@@ -376,8 +438,26 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // pair mode) do no arithmetic: their two waves keep copying their share of every chunk and meet every barrier, so the
     // other wave of each SIMD has the matrix pipe to itself for that tile.
     const bool active = ty * REG + 16 * by < p.H && (pair ? 0 : tx * REG + 16 * bx) < p.W && n + (pair ? bx : 0) < p.N;
+    // fused 1x1 epilogue, cout-major accumulators: per tile block a table [16 pixels of a tile (a, b)][16 tiles][8 partial sums
+    // (jh, q) + 1 pad]; one thread per pixel adds the 8 terms in a fixed order
+    constexpr int DSTR_S = 256 * 9;                       // floats per tile block
+    auto dot_sums_swp = [&]() {
+        const int lt = wave * 64 + lane_id();
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int P = k * NT + lt;                  // pixel of the 32x32 tile: block P >> 8, row (P >> 4) & 15, column P & 15
+            const int blk = P >> 8, yy_ = (P >> 4) & 15, xx_ = P & 15;
+            const float *s0 = smem + blk * DSTR_S + ((((yy_ & 3) * 4 + (xx_ & 3)) * 16) + (yy_ >> 2) * 4 + (xx_ >> 2)) * 9;
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sum += s0[i];
+            const int gy = ty * REG + 16 * (blk >> 1) + yy_, gx = tx * REG + (pair ? 0 : 16 * (blk & 1)) + xx_;
+            const int nn = n + (pair ? (blk & 1) : 0);
+            if (gy < p.H && gx < p.W && nn < p.N) p.dot_out[(((size_t)ct * p.N + nn) * p.H + gy) * p.W + gx] = sum;
+        }
+    };
     constexpr int DSTR = 256 * 17 + 32;                 // fused 1x1 epilogue: floats per wave, [pixel][17] + 8 of skew per tile row
-    auto dot_sums = [&]() {                             // one thread per pixel adds the 2 x 16 terms of its pixel (fixed order)
+    auto dot_sums_std = [&]() {                             // one thread per pixel adds the 2 x 16 terms of its pixel (fixed order)
         const int lt = wave * 64 + lane_id();
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -393,6 +473,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             const int nn = n + (pair ? (blk & 1) : 0);
             if (gy < p.H && gx < p.W && nn < p.N) p.dot_out[(((size_t)ct * p.N + nn) * p.H + gy) * p.W + gx] = sum;
         }
+    };
+    auto dot_sums = [&]() {
+        if constexpr (SWP) dot_sums_swp();
+        else dot_sums_std();
     };
     if (LEAN && !active) {                              // (the plain variant's register allocation suffers from this branch: -3 %)
         for (int c = 0; c < p.nchunk; ++c) {
@@ -452,9 +536,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         const int nb = (c + 1) & 1;
         const float *sA = smem + (c & 1) * IMG;
         const float *sB = sA + HSLOTS * 4;
+        f32x4 u[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if (h == 1 && more2) W4_HALO_BEGIN(c + 2);
+            // B fragments: one ds_read_b128 per group of two positions x two cout blocks, read one group ahead of its MFMAs
+#define W4_LOADU_H(dst, g, hh) dst = *(lds4_cv_f32x4 *)(sB + b_lane + ((g) * 2 + (hh)) * 256)
+#define W4_LOADU(dst, g) W4_LOADU_H(dst, g, h)
+#define W4_LANDED(x) asm volatile("" ::"v"(x.w))
+            if (W4_EARLY_U && !(abl & 16) && !(W4_PRE_U1 && h == 1)) {     // the first fragment flies under the transform below
+                W4_LOADU(u[0], 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             float V[18];                                // [row i of the transform domain][own column]
             if (abl & 2) {
 #pragma unroll
@@ -497,14 +590,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 for (int i = 0; i < 18; ++i) asm volatile("" : "+v"(V[i]));
 #endif
             }
-            // B fragments: one ds_read_b128 per group of two positions x two cout blocks, read one group ahead of its
-            // MFMAs (the empty asm consumes the landed fragment, so the next read is issued behind that wait and flies
+            // (the empty asm of W4_LANDED consumes the landed fragment, so the next read is issued behind that wait and flies
             // under the MFMAs)
-            f32x4 u[2];
-#define W4_LOADU(dst, g) dst = *(lds4_cv_f32x4 *)(sB + b_lane + ((g) * 2 + h) * 256)
-#define W4_LANDED(x) asm volatile("" ::"v"(x.w))
             if (abl & 16) u[0] = u[1] = f32x4{(float)lane, 1.f, 2.f, 3.f};
-            else W4_LOADU(u[0], 0);
+            else if (!W4_EARLY_U && !(W4_PRE_U1 && h == 1)) W4_LOADU(u[0], 0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int g = 0; g < 9; ++g) {
@@ -518,23 +607,35 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    acc[s & 1][2 * g + (s >> 1)] =
-                        __builtin_amdgcn_mfma_f32_16x16x4f32(V[2 * g + (s >> 1)], u[g & 1][s], acc[s & 1][2 * g + (s >> 1)], 0, 0, 0);
+                for (int s = 0; s < 4; ++s) {
+                    // SWP: D[cout][tile] -- register i of lane (ti, q) is cout 4q + i of tile ti (the operands' lane layouts are
+                    // the same, so swapping them hands the epilogue 4 consecutive couts per lane at no cost here)
+                    if constexpr (SWP)
+                        acc[s & 1][2 * g + (s >> 1)] =
+                            __builtin_amdgcn_mfma_f32_16x16x4f32(u[g & 1][s], V[2 * g + (s >> 1)], acc[s & 1][2 * g + (s >> 1)], 0, 0, 0);
+                    else
+                        acc[s & 1][2 * g + (s >> 1)] =
+                            __builtin_amdgcn_mfma_f32_16x16x4f32(V[2 * g + (s >> 1)], u[g & 1][s], acc[s & 1][2 * g + (s >> 1)], 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 if (h == 1 && !(abl & 2)) {                 // unconditional (the last chunk reads a stale image): no branch, exact waitcnts
                     if (g >= W4_PATCH_FIRST) read_patch(nb, W4_PATCH_READS * (g - W4_PATCH_FIRST), W4_PATCH_READS * (g - W4_PATCH_FIRST + 1));
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-#undef W4_LOADU
-#undef W4_LANDED
             if (h == 0) {                               // barrier between the passes
+                if (W4_PRE_U1 && !(abl & 16)) {          // the U slab of this chunk is complete: the second pass's first fragment
+                    W4_LOADU_H(u[0], 0, 1);              // is requested on this side of the barrier
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 if (more) W4_U_END();
                 W4_WAIT_MID();
                 if (!(abl & 8)) __builtin_amdgcn_s_barrier();
             }
         }
+#undef W4_LOADU
+#undef W4_LOADU_H
+#undef W4_LANDED
         if (more2) W4_HALO_END();
         W4_WAIT_END(more2);                             // image c's U half is free behind this barrier, image c + 1 complete
         if (!(abl & 8)) __builtin_amdgcn_s_barrier();
@@ -562,9 +663,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // Y = A^T M A = sum over the transform-domain columns j of (A^T M)[.][j] * A^T[v][j]: each wave forms the sum over its
     // own three columns for both cout blocks, hands the partner's block over through LDS (the images are free: the loop
     // ended with a barrier) and finishes its own: lane (ti, q) = cout 16*jh + ti of the tiles (row q, columns r = 0..3).
-    const int el = LEAN ? lane_id() : lane;             // LEAN: lane-derived values are recomputed here (see lane_id)
+    // (SWP: lane = (tile eti of the tile block, couts 4 eq .. 4 eq + 3 of a cout block) instead)
+    const int el = (LEAN || SWP) ? lane_id() : lane;    // LEAN: lane-derived values are recomputed here (see lane_id)
     const int eti = el & 15, eq = el >> 4;
-    const float bias_r = LEAN ? p.bias[ct * 32 + 16 * jh + eti] : bias_pre;
+    const float bias_r = W4_BIAS_ACC ? 0.f : LEAN ? p.bias[ct * 32 + 16 * jh + eti] : bias_pre;
+    (void)bias_r;
     auto partial = [&](const f32x4 *m, int r, float (&y)[4][4]) {
         float w[4][3];
 #pragma unroll
@@ -598,6 +701,80 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
     __syncthreads();
     const float *xr = smem + ((tb * 2 + (jh ^ 1)) * 16 * 64 + el) * 4;  // the partner's block: its sum for OUR cout block
+    if constexpr (SWP) {
+        // Register r of the partial sums is cout 4 eq + r of tile eti: the 4x4 pixels of the tile x 4 consecutive couts leave
+        // as 16-byte stores (half a channel block of the C8 layout per lane, 16 stores per lane instead of 64).
+        const int etyl = eti >> 2, etxl = eti & 3;
+        const int gyt = ty * REG + 16 * by + 4 * etyl, gxt = tx * REG + (pair ? 0 : 16 * bx) + 4 * etxl;   // the tile's first pixel
+        float yy[4][4][4];                              // [cout r][row a][column b]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            partial(acc[0], r, yy[r]);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const f32x4 o = *reinterpret_cast<const f32x4 *>(xr + (r * 4 + a) * 256);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) yy[r][a][b] = fmaxf(yy[r][a][b] + o[b], 0.f);
+            }
+        }
+        if constexpr (EPI == CONV3X3_RELU_DOT) {
+            // Fused last layer (model.py:91,93): out[px] += sum over this workgroup's 32 couts of w1x1[c] * ReLU(conv[c][px] + bias[c]);
+            // the 64-channel tensor is never written.  Each lane adds its 4 couts, the 4 cout quads of a wave and the two waves of
+            // a tile block meet in LDS ([pixel][8 + pad]) and one thread per pixel adds the 8 terms in a fixed order:
+            // deterministic, no atomics.  launch_dot_finish adds the planes of the cout tiles + bias.
+            const f32x4 wd = *reinterpret_cast<const f32x4 *>(p.dotw + ct * 32 + 16 * jh + 4 * eq);
+            __syncthreads();                            // every wave has read its partner's exchange block
+            float *dw = smem + tb * DSTR_S + eti * 9 + jh * 4 + eq;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    dw[(a * 4 + b) * 16 * 9] = ((wd[0] * yy[0][a][b] + wd[1] * yy[1][a][b]) + wd[2] * yy[2][a][b]) + wd[3] * yy[3][a][b];
+            __syncthreads();
+            dot_sums();
+            return;
+        }
+        const int nb = n + (pair ? bx : 0);             // pair mode: the tile blocks of column 1 belong to the next clip
+        const bool clip_ok = nb < p.N;
+        const int Hp = p.H >> 1, Wp = p.W >> 1;
+        const int cblk = ct * 4 + 2 * jh + (eq >> 1), coff = 4 * (eq & 1);      // C8 block and offset of this lane's 4 couts
+        float *ob = static_cast<float *>(p.out) + (size_t)nb * p.H * p.W * p.Cout + (size_t)cblk * p.H * p.W * 8 + coff;
+        float *pb = (EPI == CONV3X3_RELU_POOL)
+                        ? static_cast<float *>(p.pool) + (size_t)nb * Hp * Wp * p.Cout + (size_t)cblk * Hp * Wp * 8 + coff
+                        : nullptr;
+        const bool interior = W4_EPI_FAST && clip_ok && ty * REG + 16 * by + 16 <= p.H && tx * REG + (pair ? 0 : 16 * bx) + 16 <= p.W;   // wave-uniform
+        auto finish = [&](auto interior_tag) {          // tile blocks wholly inside the image store without bounds checks
+            constexpr bool INT = decltype(interior_tag)::value;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                float *orow = ob + ((size_t)(gyt + a) * p.W + gxt) * 8;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const f32x4 v = {yy[0][a][b], yy[1][a][b], yy[2][a][b], yy[3][a][b]};
+                    if ((ABL & 4096) && v[0] != 123.456f) continue;
+                    if (INT || (clip_ok && gyt + a < p.H && gxt + b < p.W)) *reinterpret_cast<f32x4 *>(orow + b * 8) = v;
+                }
+            }
+            if (EPI == CONV3X3_RELU_POOL) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const int py = (gyt >> 1) + a;
+                    float *prow = pb + ((size_t)py * Wp + (gxt >> 1)) * 8;
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        f32x4 m;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            m[r] = fmaxf(fmaxf(yy[r][2 * a][2 * b], yy[r][2 * a][2 * b + 1]), fmaxf(yy[r][2 * a + 1][2 * b], yy[r][2 * a + 1][2 * b + 1]));
+                        if ((ABL & 4096) && m[0] != 123.456f) continue;
+                        if (INT || (clip_ok && py < Hp && (gxt >> 1) + b < Wp)) *reinterpret_cast<f32x4 *>(prow + b * 8) = m;
+                    }
+                }
+            }
+        };
+        if (interior) finish(std::true_type{});
+        else finish(std::false_type{});
+    } else {
     const int Hp = p.H >> 1, Wp = p.W >> 1;
     const int col = ct * 32 + 16 * jh + eti;
     if constexpr (EPI == CONV3X3_RELU_DOT) {
@@ -614,7 +791,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             for (int a = 0; a < 4; ++a) {
                 const f32x4 o = *reinterpret_cast<const f32x4 *>(xr + (r * 4 + a) * 256);
 #pragma unroll
-                for (int b = 0; b < 4; ++b) yf[r][a][b] = wdot * fmaxf(yf[r][a][b] + o[b] + bias_r, 0.f);
+                for (int b = 0; b < 4; ++b) yf[r][a][b] = wdot * fmaxf(W4_BIAS_ACC ? yf[r][a][b] + o[b] : yf[r][a][b] + o[b] + bias_r, 0.f);
             }
         }
         __syncthreads();                                // every wave has read its partner's exchange block
@@ -658,7 +835,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 const f32x4 o = *reinterpret_cast<const f32x4 *>(xr + (r * 4 + a) * 256);
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
-                    y[a][b] = fmaxf(y[a][b] + o[b] + bias_r, 0.f);
+                    y[a][b] = fmaxf(W4_BIAS_ACC ? y[a][b] + o[b] : y[a][b] + o[b] + bias_r, 0.f);
                     if constexpr (INT) {
                         if (!(ABL & 4096) || y[a][b] == 123.456f) orow[a][(4 * r + b) * 8] = y[a][b];
                     } else {
@@ -685,6 +862,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     };
     if (interior) finish(std::true_type{});
     else finish(std::false_type{});
+    }   // !SWP
 #ifdef ADN_EXPERIMENTS
     if (p.dbg && wave == 0) {
         const unsigned long long tl3 = __builtin_amdgcn_s_memtime();
@@ -731,6 +909,16 @@ hipError_t launch_wino4_conv(ConvKind kind, const ConvArgs &a, hipStream_t st)
     const long ptiles = (long)((a2.N + a2.pair) >> a2.pair) * a2.tilesY * a2.tilesX;
     const long nwg = ((ptiles + gp - 1) / gp) * gp * a2.nct;
     if (nwg <= 0 || nwg > 0x7fffffffL) return hipErrorInvalidValue;
+    // reciprocals for the kernel's tile decode; plain division (fdGc.d = 0) where SUP / gc is not exact or an index times its
+    // divisor could leave 32 bits
+    a2.fdGc = a2.fdNcg = a2.fdTx = a2.fdTy = FastDiv{0u, 0u};
+    const long maxd = std::max<long>(std::max<long>(gc, a2.nct / gc), std::max<long>(a2.tilesX, a2.tilesY));
+    if (gc * gp == SUP && a2.nct % gc == 0 && (unsigned long long)nwg * (unsigned long long)maxd < 0x100000000ull) {
+        a2.fdGc = make_fastdiv((unsigned)gc);
+        a2.fdNcg = make_fastdiv((unsigned)(a2.nct / gc));
+        a2.fdTx = make_fastdiv((unsigned)a2.tilesX);
+        a2.fdTy = make_fastdiv((unsigned)a2.tilesY);
+    }
     a2.ablate = 0;
 #ifdef ADN_EXPERIMENTS
     { const char *ab = std::getenv("ADN_WINO4_ABLATE"); a2.ablate = ab ? std::atoi(ab) : 0; }   // timing experiments only

@@ -113,12 +113,13 @@ class WavToSpecDataset(Dataset):
       ``subset=`` takes the ``Subset`` objects of ``random_split(ds, ...)`` (``train.py:111-114``) or a list of indices.
     * ``load_batch_to_device(indices)``: the same without a DataLoader.
 
-    ``ds[i]`` transforms the WHOLE file and crops the spectrogram; the loader crops / zero-pads the AUDIO to
+    ``ds[i]`` transforms the WHOLE file and crops / zero-pads the spectrogram; the loader crops / zero-pads the AUDIO to
     ``clip_samples`` first.  Both give the same item when ``clip_samples >= min_clip_samples()`` =
-    ``(W - 1) * hop + n_fft // 2``: then every frame inside ``target_size`` sees the same samples (the centre padding is
-    zeros, so a file shorter than ``clip_samples`` agrees as well).  Below that bound a file longer than ``clip_samples``
-    loses samples the last frames would have seen; :meth:`audio_view` / :meth:`loader` refuse it unless
-    ``allow_cut_frames=True``.
+    ``(W - 1) * hop + n_fft // 2``: then every frame inside ``target_size`` sees the same samples, and for a file SHORTER
+    than ``clip_samples`` the frames that do not exist in its own STFT (index > L // hop; they would overlap the file's tail
+    in the padded audio) are zeroed on the device from the true length the view hands along -- the loader rule's right
+    zero-padding.  Below that bound a file longer than ``clip_samples`` loses samples the last frames would have seen;
+    :meth:`audio_view` / :meth:`loader` refuse it unless ``allow_cut_frames=True``.
 
     No resampling: ``sample_rate`` (if given) is checked against each file.
     """
@@ -195,11 +196,20 @@ class WavToSpecDataset(Dataset):
         return _WavAudioView(self, clip_samples)
 
     def to_device_batch(self, host_batch):
-        """``(noisy_audio (B, L), clean_audio (B, L))`` host tensors (what a DataLoader over :meth:`audio_view` yields)
-        -> ``(noisy, clean)`` each ``(B, 1, H, W)`` float32 on the device: one batched STFT + quantise + crop/pad per
-        side.  Must run in the process that owns the GPU context (the DataLoader's consumer, not its workers)."""
-        noisy, clean = host_batch
-        return self._spec_batch(noisy), self._spec_batch(clean)
+        """``(noisy_audio (B, L), clean_audio (B, L), noisy_len (B,), clean_len (B,))`` host tensors (what a DataLoader
+        over :meth:`audio_view` yields; the lengths are the files' true sample counts) -> ``(noisy, clean)`` each
+        ``(B, 1, H, W)`` float32 on the device: one batched STFT + quantise + crop/pad per side, then the frames a short
+        file's own STFT does not have (index > len // hop) are zeroed.  Must run in the process that owns the GPU context
+        (the DataLoader's consumer, not its workers)."""
+        noisy, clean = host_batch[0], host_batch[1]
+        out = [self._spec_batch(noisy), self._spec_batch(clean)]
+        if len(host_batch) >= 4:
+            frames = torch.arange(self.target_size[1], device=out[0].device)
+            for k in range(2):
+                nfr = 1 + torch.as_tensor(host_batch[2 + k]).to(out[k].device).clamp(max=noisy.shape[1]) // self.hop_length
+                keep = frames[None, :] < nfr[:, None]                       # (B, W)
+                out[k] = torch.where(keep[:, None, None, :], out[k], torch.zeros((), device=out[k].device))
+        return out[0], out[1]
 
     def loader(self, clip_samples: int, subset=None, allow_cut_frames: bool = False, **dataloader_kwargs):
         """Iterable with the ``DataLoader`` call shape of ``train.py:118-119`` (``batch_size``, ``shuffle``,
@@ -255,4 +265,5 @@ class _WavAudioView(Dataset):
 
     def __getitem__(self, idx):
         noisy_path, clean_path = self.parent.pairs[idx]
-        return self._fit(self.parent._audio(noisy_path)), self._fit(self.parent._audio(clean_path))
+        noisy, clean = self.parent._audio(noisy_path), self.parent._audio(clean_path)
+        return self._fit(noisy), self._fit(clean), len(noisy), len(clean)

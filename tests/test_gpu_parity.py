@@ -444,6 +444,13 @@ def test_stft_config2_full_size_10000_clips(dev):
     (5000, 256, 64, True, (200, 100)),          # pad rows (129 < 200) and frames (79 < 100)
     (6000, 2048, 512, True, (513, 8)),          # workgroup-synchronous kernel (n_fft > 1024), crop rows and frames
     (3000, 64, 16, True, (33, 188)),
+    # the persistent whole-line kernel (n_fft 256 / 512 / 1024): windows that are not multiples of 4 or 32 frames (scalar
+    # store tail), odd clip lengths (clips alternate 8-byte alignment), a hop that is not n_fft / 4, fewer rows than bins
+    (132301, 1024, 256, True, (513, 250)),
+    (40001, 1024, 200, True, (300, 131)),
+    (24001, 512, 128, True, (257, 67)),
+    (9000, 256, 64, False, (129, 97)),
+    (20000, 512, 100, False, (100, 33)),
 ])
 def test_stft_mag_fit_equals_stft_then_loader_rule(dev, L, n_fft, hop, center, target):
     """adn_stft_mag_fit = adn_quantize_pad(adn_stft_mag(...)) in one kernel, bit for bit (it only skips the frames and
@@ -461,6 +468,27 @@ def test_stft_mag_fit_equals_stft_then_loader_rule(dev, L, n_fft, hop, center, t
     got = fused[1, 0].cpu().numpy()
     assert np.max(np.abs(got - ref)) <= 2.0 ** -10 * np.max(np.abs(ref))       # one fp16 ulp where roundings straddle
     assert (got != ref).mean() < 5e-3
+
+
+def test_stft_mag_fit_persistent_runs_many_clips(dev):
+    """The persistent kernel of adn_stft_mag_fit at a size where every workgroup walks a run of several (clip, group) items
+    that crosses clip boundaries: 700 clips x 8 groups over 768 resident workgroups.  Bit-identical to the two-step form, and
+    every clip independent of its neighbours (a clip computed alone gives the same bits)."""
+    from audiodenoiser_amd.data_loader import quantize_pad_on_device
+    from audiodenoiser_amd.stft import stft_magnitude, stft_magnitude_fit
+    g = torch.Generator(device=dev).manual_seed(4)
+    a = torch.rand((700, 132300), generator=g, device=dev) * 2 - 1
+    fused = stft_magnitude_fit(a, (513, 256), 1024, 256, True)
+    for lo in (0, 350):
+        two_step = quantize_pad_on_device(stft_magnitude(a[lo:lo + 350], 1024, 256, True), (513, 256))
+        assert torch.equal(fused[lo:lo + 350], two_step)
+        del two_step
+    for i in (0, 1, 313, 699):
+        assert torch.equal(stft_magnitude_fit(a[i:i + 1].clone(), (513, 256), 1024, 256, True)[0], fused[i])
+    # the reference's own setting (n_fft 512 / hop 128, 3 s @ 8 kHz -> 257 x 188 cropped to the loader default 256 x 64)
+    b = torch.rand((3000, 24000), generator=g, device=dev) * 2 - 1
+    f2 = stft_magnitude_fit(b, (256, 64), 512, 128, True)
+    assert torch.equal(f2, quantize_pad_on_device(stft_magnitude(b, 512, 128, True), (256, 64)))
 
 
 def test_stft_rejects_bad_arguments(dev):

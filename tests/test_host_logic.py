@@ -342,11 +342,13 @@ def test_wav_dataset_worker_guard_and_audio_view(tmp_path):
     assert len(view) == 4
     batches = list(DataLoader(view, batch_size=2, num_workers=2))
     assert len(batches) == 2
-    for noisy, clean in batches:
+    for noisy, clean, n_len, c_len in batches:
         assert noisy.shape == clean.shape == (2, 1000) and noisy.dtype == torch.float32
-    n0, _ = view[0]                                       # 900 samples -> zero padded at the end
+        assert n_len.shape == c_len.shape == (2,)
+    assert [int(v) for b in batches for v in b[2]] == [900, 1200, 700, 1000]      # the files' true lengths travel along
+    n0 = view[0][0]                                       # 900 samples -> zero padded at the end
     assert float(n0[900:].abs().max()) == 0.0 and float(n0[:900].abs().max()) > 0.0
-    n1, _ = view[1]                                       # 1200 samples -> cropped
+    n1 = view[1][0]                                       # 1200 samples -> cropped
     from audiodenoiser_amd.wav import read_wav
     assert np.array_equal(n1.numpy(), read_wav(str(tmp_path / "noisy_1.wav"))[0][:1000])
     with pytest.raises(ValueError):

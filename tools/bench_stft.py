@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cpu-clips", type=int, default=64)
+    ap.add_argument("--fit", action="store_true", help="also time adn_stft_mag_fit (the same clips -> (clips,1,513,256))")
     args = ap.parse_args()
     from audiodenoiser_amd import _lib
     from audiodenoiser_amd.stft import stft_n_frames
@@ -55,6 +56,25 @@ def main():
            "frames_per_s": round(args.clips * nfr / (ms * 1e-3), 1),
            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
                         "frac": round(gbs / 8000.0, 4), "bytes_per_clip": bytes_per_clip}}
+    if args.fit:
+        H, W = args.n_fft // 2 + 1, 256
+        fit = torch.empty((args.clips, 1, H, W), dtype=torch.float32, device=dev)
+
+        def run_fit():
+            _lib.check(L.adn_stft_mag_fit(a.data_ptr(), args.clips, args.length, args.n_fft, args.hop, 1, fit.data_ptr(), H, W, st),
+                       "adn_stft_mag_fit")
+        for _ in range(args.warmup):
+            run_fit()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(args.steps):
+            run_fit()
+        e1.record()
+        torch.cuda.synchronize()
+        ms_fit = e0.elapsed_time(e1) / args.steps
+        fit_bytes = args.clips * ((W - 1) * args.hop + args.n_fft // 2 + H * W) * 4
+        res["fit"] = {"ms_per_launch": round(ms_fit, 4), "algorithmic_GBps": round(fit_bytes / (ms_fit * 1e-3) / 1e9, 1),
+                      "frac": round(fit_bytes / (ms_fit * 1e-3) / 1e9 / 8000.0, 4), "bytes": fit_bytes}
     if args.cpu_clips > 0:
         import oracle
         host = a[:args.cpu_clips].cpu().numpy()
