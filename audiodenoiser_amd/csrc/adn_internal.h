@@ -56,7 +56,7 @@ struct FastDiv {
 };
 inline FastDiv make_fastdiv(unsigned d) { return FastDiv{d, d > 1 ? (unsigned)((0x100000000ull + d - 1) / d) : 0u}; }
 #ifdef __HIPCC__
-__device__ __forceinline__ int fastdiv(int n, FastDiv f) { return f.d == 1 ? n : (int)__umulhi((unsigned)n, f.m); }
+__device__ __forceinline__ int fastdiv(int n, unsigned d, unsigned m) { return d == 1 ? n : (int)__umulhi((unsigned)n, m); }
 #endif
 
 // Arguments of the matrix-core convolution kernels (3x3 convolution or 2x2-stride-2 transposed convolution).
@@ -73,6 +73,7 @@ struct ConvArgs {
     int tilesY, tilesX, nct;
     int pair;              // wino4_conv_f32 only: 1 = a workgroup tile holds two clips side by side (images <= 16 px wide)
     FastDiv fdGc, fdNcg, fdTx, fdTy;   // wino4_conv_f32 only: the divisors of its tile decode (fdGc.d == 0: plain division)
+    int nwg_total;         // wino4_conv_f32 only: logical workgroup ids (= tiles incl. supertile padding) of the launch
     int ablate;            // timing experiments only (ADN_WINO_ABLATE); 0 in production
     const float *zeros;    // >= 16 bytes of zeros in device memory (source of padding lanes of the LDS-DMA copy)
     void *dbg;             // diagnostic stamp buffer (ADN_WINO_STAMP); nullptr in production

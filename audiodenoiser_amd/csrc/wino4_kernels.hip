@@ -62,6 +62,21 @@ constexpr int KC = 8;                        // input channels per chunk
 #ifndef W4_SWAP
 #define W4_SWAP 2
 #endif
+// W4_PERSIST: 1 = one workgroup per CU walks its XCD's share of the logical workgroup ids (tile after tile, nothing overlapped:
+// the next tile's index arithmetic and first copies start behind the current tile's last store) instead of one workgroup per
+// tile: removes the gap between workgroups on a CU (1500-3300 clocks), the kernel-argument loads and the launch skew of the 8
+// waves (~2000 clocks at the first barrier) from every tile but the first (profiles/r02_wino4_timeline.txt).  Parity-green, but
+// measured 2.3 % SLOWER per batch-64 step (35.03 vs 34.23 ms, profiles/r03_wino4_variants.txt): inside the tile loop hipcc's K
+// loop carries ~150 v_mov per chunk (register copies of the patch that is read one chunk ahead) that the one-tile form does
+// not have, and 6 VGPRs + 20 SGPRs spill per tile.  Not used.
+#ifndef W4_PERSIST
+#define W4_PERSIST 0
+#endif
+#if W4_PERSIST
+#define W4_TILE_DONE break
+#else
+#define W4_TILE_DONE return
+#endif
 #ifndef W4_EARLY_U                            // 1: a pass's first B fragment is requested before its input transform, not behind it (-0.2 %)
 #define W4_EARLY_U 1
 #endif
@@ -209,14 +224,23 @@ static_assert(W4_PR * (9 - W4_PR0) >= 30, "the second pass must issue all 30 pat
 // copy reads the zero block, 256 contiguous (L1-resident) stand-in for the halo gather, 2048 no epilogue, 4096 no global
 // stores in the epilogue, 8192 first chunk's copies not awaited (prologue latency); results are wrong by design.  0 in production.
 template <int EPI, int ABL = 0, int PL = w4_default_placement(EPI)>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino4_conv_f32(const ConvArgs p)
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino4_conv_f32(const ConvArgs p_)
 {
+#if W4_PERSIST
+    // The arguments are re-read from the kernel-argument segment (scalar loads, scalar-cache hits) by every tile: kept live
+    // across the tile loop they would occupy ~60 SGPRs the K loop needs (measured: 100 SGPR + 40 VGPR spills).
+    typedef const ConvArgs __attribute__((address_space(4))) KArgs;
+    KArgs *pa = (KArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    (void)p_;
+#else
+    const ConvArgs &p = p_;
+#endif
     extern __shared__ __attribute__((aligned(16))) float smem[];   // the ONLY LDS object (two images)
     // Two source forms of the same arithmetic, chosen per epilogue by measurement (hipcc's register allocation of the K loop
     // is sensitive to what has to survive it): LEAN keeps nothing thread-id-derived alive across the loop (no scratch
     // spills: the pooling and fused-1x1 variants run 4-6 % faster); the plain variant is faster (up to 6 %) in the other
     // form, which spills 7 registers once per workgroup.
-    constexpr bool LEAN = EPI != CONV3X3_RELU;
+    constexpr bool LEAN = W4_PERSIST || EPI != CONV3X3_RELU;     // (the persistent form has no registers to spare: LEAN for all)
     constexpr bool SWP = W4_SWAP == 1 || (W4_SWAP == 2 && EPI == CONV3X3_RELU_DOT);      // cout-major accumulators (W4_SWAP above)
 
 #ifdef ADN_EXPERIMENTS
@@ -240,20 +264,33 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // workgroup -> (pixel tile, cout tile): SUP consecutive ids (after the XCD remap) run together on one XCD and form
     // a supertile of gc cout tiles x gp pixel tiles, so every U slab and every halo is an L2 hit for all but one of them
     // (gc = as many cout tiles as there are, up to all 32 slots: measured 0.5 % faster than capping gc at 8)
+#if W4_PERSIST
+    // workgroup b sits on XCD b & 7 (observed round-robin placement; speed only) in slot b >> 3 and walks the ids of that XCD's
+    // range in steps of the slot count: the same 32 ids run together on an XCD as in a one-tile-per-workgroup launch
+    const int xq_ = pa->nwg_total >> 3, xr_ = pa->nwg_total & 7, xcd_ = blockIdx.x & 7;
+    const int lstart = xcd_ < xr_ ? xcd_ * (xq_ + 1) : xr_ * (xq_ + 1) + (xcd_ - xr_) * xq_;
+    const int lend = lstart + xq_ + (xcd_ < xr_ ? 1 : 0), lstep = (int)(gridDim.x >> 3);
+#pragma clang loop unroll(disable)
+    for (int lid = lstart + (int)(blockIdx.x >> 3); lid < lend; lid += lstep) {
+    asm volatile("" : "+s"(pa));                          // (opaque per tile: nothing loaded through it is hoisted out of the loop)
+    KArgs &p = *pa;
+    do {
+#else
     const int lid = xcd_remap4(blockIdx.x, gridDim.x);
+#endif
     const int pair = p.pair;                              // 1: two clips side by side in the tile (see RSL above)
     int ct, pt, tx, ty, n;
     if (W4_FASTDIV && p.fdGc.d) {
         // the seven divisions of the decode cost ~1000 clocks of every workgroup's start as software divides; the divisors are
         // launch constants, so the launcher passes their reciprocals (FastDiv, adn_internal.h)
         const int gc = p.fdGc.d, sg = lid >> 5, wl = lid & (SUP - 1);
-        const int wq = fastdiv(wl, p.fdGc), sq = fastdiv(sg, p.fdNcg);
+        const int wq = fastdiv(wl, p.fdGc.d, p.fdGc.m), sq = fastdiv(sg, p.fdNcg.d, p.fdNcg.m);
         ct = (sg - sq * (int)p.fdNcg.d) * gc + (wl - wq * gc);
         pt = sq * (SUP / gc) + wq;
-        if (pt >= ((p.N + pair) >> pair) * p.tilesY * p.tilesX) return;   // padding of the last supertile (whole workgroup exits)
-        const int py = fastdiv(pt, p.fdTx);
+        if (pt >= ((p.N + pair) >> pair) * p.tilesY * p.tilesX) W4_TILE_DONE;   // padding of the last supertile (whole workgroup)
+        const int py = fastdiv(pt, p.fdTx.d, p.fdTx.m);
         tx = pt - py * p.tilesX;
-        const int pn = fastdiv(py, p.fdTy);
+        const int pn = fastdiv(py, p.fdTy.d, p.fdTy.m);
         ty = py - pn * p.tilesY;
         n = pn << pair;
     } else {
@@ -262,7 +299,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         const int sg = lid / SUP, wl = lid - sg * SUP;
         ct = (sg % ncg) * gc + wl % gc;
         pt = (sg / ncg) * gp + wl / gc;
-        if (pt >= ((p.N + pair) >> pair) * p.tilesY * p.tilesX) return;   // padding of the last supertile (whole workgroup exits)
+        if (pt >= ((p.N + pair) >> pair) * p.tilesY * p.tilesX) W4_TILE_DONE;   // padding of the last supertile (whole workgroup)
         tx = pt % p.tilesX;
         pt /= p.tilesX;
         ty = pt % p.tilesY;
@@ -287,7 +324,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 
     // DMA plan of the halo: slot s = r*NT + tid -> (row, pixel, channel half); byte offsets into the current source, OOB = zeros
     unsigned hcur[HR];                                  // byte offsets inside the source image(s), OOB = padding
-    auto plan = [&](const ConvSrc &s, int r0 = 0, int r1 = HR) {
+    auto plan = [&](const auto &s, int r0 = 0, int r1 = HR) {
         // LEAN variants: thread id rebuilt from the lane id and the plan of the second source kept inside the loop (the empty
         // asm stops its hoisting), so that neither survives the K loop in registers
         int t_ = LEAN ? wave * 64 + lane_id() : tid;
@@ -311,7 +348,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     };
     if (!W4_EARLY_HALO) plan(p.s0);
     // descriptor of the current source: the image of clip n (pair mode: clips n, n + 1); soff walks its 8-channel blocks
-    auto src_rsrc = [&](const ConvSrc &s) {
+    auto src_rsrc = [&](const auto &s) {
         const unsigned img = (unsigned)(s.C * s.H * s.W) * 4u;
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(static_cast<const float *>(s.ptr)) + (size_t)n * s.H * s.W * s.C, 0,
                                                  img << pair, 0x00020000);
@@ -498,14 +535,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             if (!(ABL & 8)) __builtin_amdgcn_s_barrier();
         }
         __syncthreads();                                // the images are free for the epilogue
-        if constexpr (ABL & 2048) return;
+        if constexpr (ABL & 2048) W4_TILE_DONE;
         __syncthreads();                                // epilogue: exchange blocks written
         if constexpr (EPI == CONV3X3_RELU_DOT) {
             __syncthreads();
             __syncthreads();
             dot_sums();
         }
-        return;
+        W4_TILE_DONE;
     }
 
     constexpr int abl = ABL;
@@ -657,7 +694,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
         for (int s2 = 0; s2 < 18; ++s2) keep += acc[0][s2][0] + acc[1][s2][1];
         if (keep == 123.456f) static_cast<float *>(p.out)[tid] = keep;
-        return;
+        W4_TILE_DONE;
     }
     // ---- epilogue ----
     // Y = A^T M A = sum over the transform-domain columns j of (A^T M)[.][j] * A^T[v][j]: each wave forms the sum over its
@@ -732,7 +769,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     dw[(a * 4 + b) * 16 * 9] = ((wd[0] * yy[0][a][b] + wd[1] * yy[1][a][b]) + wd[2] * yy[2][a][b]) + wd[3] * yy[3][a][b];
             __syncthreads();
             dot_sums();
-            return;
+            W4_TILE_DONE;
         }
         const int nb = n + (pair ? bx : 0);             // pair mode: the tile blocks of column 1 belong to the next clip
         const bool clip_ok = nb < p.N;
@@ -804,7 +841,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 for (int b = 0; b < 4; ++b) dw[((4 * eq + a) * 16 + 4 * r + b) * 17] = yf[r][a][b];
         __syncthreads();
         dot_sums();
-        return;
+        W4_TILE_DONE;
     }
     const int nb = n + (pair ? bx : 0);                 // pair mode: the tile blocks of column 1 belong to the next clip
     const bool clip_ok = nb < p.N;
@@ -863,15 +900,22 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if (interior) finish(std::true_type{});
     else finish(std::false_type{});
     }   // !SWP
+#if W4_PERSIST
+    } while (0);
+    // every wave has read its partner's exchange block (and the fused-1x1 table): the images may be refilled.  The stores of
+    // this tile are still draining; the next tile's first wait (vmcnt(0) in front of its first barrier) covers them.
+    __syncthreads();
+    }   // tiles of this workgroup
+#endif
 #ifdef ADN_EXPERIMENTS
-    if (p.dbg && wave == 0) {
+    if (p_.dbg && wave == 0) {
         const unsigned long long tl3 = __builtin_amdgcn_s_memtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long tl4 = __builtin_amdgcn_s_memtime();
         const unsigned hwid = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));        // HW_REG_HW_ID
         const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));        // HW_REG_XCC_ID
         if (lane == 0) {
-            unsigned long long *o = reinterpret_cast<unsigned long long *>(p.dbg) + (size_t)blockIdx.x * 8;
+            unsigned long long *o = reinterpret_cast<unsigned long long *>(p_.dbg) + (size_t)blockIdx.x * 8;
             o[0] = tl0; o[1] = tl1; o[2] = tl2; o[3] = tl3; o[4] = tl4; o[5] = ((unsigned long long)xcc << 32) | hwid;
             o[6] = ((tla - tl0) << 32) | ((tlb - tla) & 0xffffffffull); o[7] = tlc - tlb;
         }
@@ -919,6 +963,24 @@ hipError_t launch_wino4_conv(ConvKind kind, const ConvArgs &a, hipStream_t st)
         a2.fdTx = make_fastdiv((unsigned)a2.tilesX);
         a2.fdTy = make_fastdiv((unsigned)a2.tilesY);
     }
+    a2.nwg_total = (int)nwg;
+    long grid = nwg;
+#if W4_PERSIST
+    {
+        static std::atomic<int> cus{0};                   // (one device model per process: gfx950 only, checked at handle creation)
+        int c = cus.load(std::memory_order_relaxed);
+        if (c == 0) {
+            int dv = 0;
+            if (hipGetDevice(&dv) != hipSuccess || hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dv) != hipSuccess || c < 8)
+                return hipErrorInvalidDevice;
+            c &= ~7;                                       // whole slots on each of the 8 XCDs
+            cus.store(c, std::memory_order_relaxed);
+        }
+        if (nwg > c) grid = c;                            // one workgroup per CU walks the ids; small launches stay one tile per workgroup
+        else grid = (nwg + 7) & ~7L;
+        if (grid < 8) grid = 8;
+    }
+#endif
     a2.ablate = 0;
 #ifdef ADN_EXPERIMENTS
     { const char *ab = std::getenv("ADN_WINO4_ABLATE"); a2.ablate = ab ? std::atoi(ab) : 0; }   // timing experiments only
@@ -1026,11 +1088,11 @@ hipError_t launch_wino4_conv(ConvKind kind, const ConvArgs &a, hipStream_t st)
 #endif
     static_assert(8 * (256 * 17 + 32) * sizeof(float) <= LDS_BYTES, "staging of the fused 1x1 epilogue must fit the images");
     if (kind == CONV3X3_RELU_DOT)
-        hipLaunchKernelGGL(wino4_conv_f32<CONV3X3_RELU_DOT>, dim3((unsigned)nwg), dim3(NT), LDS_BYTES, st, a2);
+        hipLaunchKernelGGL(wino4_conv_f32<CONV3X3_RELU_DOT>, dim3((unsigned)grid), dim3(NT), LDS_BYTES, st, a2);
     else if (kind == CONV3X3_RELU_POOL)
-        hipLaunchKernelGGL(wino4_conv_f32<CONV3X3_RELU_POOL>, dim3((unsigned)nwg), dim3(NT), LDS_BYTES, st, a2);
+        hipLaunchKernelGGL(wino4_conv_f32<CONV3X3_RELU_POOL>, dim3((unsigned)grid), dim3(NT), LDS_BYTES, st, a2);
     else
-        hipLaunchKernelGGL(wino4_conv_f32<CONV3X3_RELU>, dim3((unsigned)nwg), dim3(NT), LDS_BYTES, st, a2);
+        hipLaunchKernelGGL(wino4_conv_f32<CONV3X3_RELU>, dim3((unsigned)grid), dim3(NT), LDS_BYTES, st, a2);
     return hipGetLastError();
 }
 
