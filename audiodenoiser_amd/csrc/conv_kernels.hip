@@ -517,31 +517,24 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void conv_dma(const ConvArgs p)
     const int hh = lane >> 5, l31 = lane & 31;
 
     int lid = xcd_remap(blockIdx.x, gridDim.x);
-    const int ct = lid % p.nct;
-    lid /= p.nct;
-    const int tx = lid % p.tilesX;
-    lid /= p.tilesX;
-    const int ty = lid % p.tilesY;
-    const int n = lid / p.tilesY;
+    int ct, tx, ty, n;
+    if (p.fdGc.d) {                                    // launch constants as reciprocals (FastDiv, adn_internal.h): no software divides
+        const int q1 = fastdiv(lid, p.fdGc.d, p.fdGc.m);                   // fdGc = nct here
+        ct = lid - q1 * p.nct;
+        const int q2 = fastdiv(q1, p.fdTx.d, p.fdTx.m);
+        tx = q1 - q2 * p.tilesX;
+        n = fastdiv(q2, p.fdTy.d, p.fdTy.m);
+        ty = q2 - n * p.tilesY;
+    } else {
+        ct = lid % p.nct;
+        lid /= p.nct;
+        tx = lid % p.tilesX;
+        lid /= p.tilesX;
+        ty = lid % p.tilesY;
+        n = lid / p.tilesY;
+    }
     const int gy0 = ty * TH - HALO, gx0 = tx * TW - HALO;
 
-    // ---- DMA plan (fixed over the chunk loop): halo slot s = r*NT + tid -> byte offset inside the source image, ADN_DMA_OOB =
-    // zeros (copies go through buffer descriptors: dma16_buf, adn_internal.h) ----
-    unsigned hcur[A_ROUNDS], hsec[A_ROUNDS];
-#pragma unroll
-    for (int r = 0; r < A_ROUNDS; ++r) {
-        const int s = r * NT + tid;
-        const int row = s / RSLOT, k = s - row * RSLOT;
-        const int pix = k / PSLOT, q = k - pix * PSLOT;
-        const bool data = s < C::A_USED && pix < PW && q < C::KQ;
-        const int gy = gy0 + row, gx = gx0 + pix;
-        const int y0 = gy - p.s0.offY, x0 = gx - p.s0.offX;
-        hcur[r] = (data && y0 >= 0 && y0 < p.s0.H && x0 >= 0 && x0 < p.s0.W)
-                      ? (unsigned)act_off<T>(p.s0.C, (long)p.s0.H * p.s0.W, y0 * p.s0.W + x0, q * EPV) * (unsigned)sizeof(T) : ADN_DMA_OOB;
-        const int y1 = gy - p.s1.offY, x1 = gx - p.s1.offX;
-        hsec[r] = (data && y1 >= 0 && y1 < p.s1.H && x1 >= 0 && x1 < p.s1.W)
-                      ? (unsigned)act_off<T>(p.s1.C, (long)p.s1.H * p.s1.W, y1 * p.s1.W + x1, q * EPV) * (unsigned)sizeof(T) : ADN_DMA_OOB;
-    }
     // descriptors: the current source image of clip n (its K-chunks are `cstr` bytes apart) and the weight slabs of this column tile
     auto src_rsrc = [&](const ConvSrc &s) {
         return dma_rsrc(static_cast<const T *>(s.ptr) + (size_t)n * s.H * s.W * s.C, (unsigned)((size_t)s.C * s.H * s.W * sizeof(T)));
@@ -552,25 +545,49 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void conv_dma(const ConvArgs p)
     unsigned cstr = (unsigned)((size_t)KG * p.s0.H * p.s0.W * ACT_BLOCK<T> * sizeof(T));
     unsigned hsoff = 0, wsoff = 0;                      // byte offsets of the next chunk inside the source image / the slabs
     const unsigned loff = lane * 16;
+    // one wave-instruction of a chunk's copy (slots [k*NT + 64*wave, +64) of image `buf`): halo part or weight part
+    unsigned hcur[A_ROUNDS];
+    auto dma_piece = [&](int k, int buf, bool want_a, bool want_b) {
+        const int sb = k * NT + wave * 64;              // first slot of this wave-instruction (uniform)
+        if (sb >= SLOTS) return;                        // tail of the last piece
+        float *dst = smem + (size_t)buf * SLOTS * 4 + sb * 4;
+        if (k < A_ROUNDS && sb < A_SLOTS) {
+            if (want_a) dma16_buf(hrs, hcur[k < A_ROUNDS ? k : 0], hsoff, dst);
+        } else if (want_b) {
+            dma16_buf(wrs, loff, wsoff + (unsigned)(sb - A_SLOTS) * 16u, dst);
+        }
+    };
+    // The weight slab of chunk 0 needs no plan: it goes out first and flies under the index arithmetic of the halo plan.
+#pragma unroll
+    for (int k = 0; k < NPIECE; ++k) dma_piece(k, 0, false, true);
+
+    // ---- DMA plan (fixed over the chunk loop): halo slot s = r*NT + tid -> byte offset inside the source image, ADN_DMA_OOB =
+    // zeros (copies go through buffer descriptors: dma16_buf, adn_internal.h).  The plan of the second source (virtual concat) is
+    // made when the K loop reaches it.
+    auto plan = [&](const ConvSrc &src) {
+#pragma unroll
+        for (int r = 0; r < A_ROUNDS; ++r) {
+            const int s = r * NT + tid;
+            const int row = s / RSLOT, k = s - row * RSLOT;
+            const int pix = k / PSLOT, q = k - pix * PSLOT;
+            const bool data = s < C::A_USED && pix < PW && q < C::KQ;
+            const int y0 = gy0 + row - src.offY, x0 = gx0 + pix - src.offX;
+            hcur[r] = (data && y0 >= 0 && y0 < src.H && x0 >= 0 && x0 < src.W)
+                          ? (unsigned)act_off<T>(src.C, (long)src.H * src.W, y0 * src.W + x0, q * EPV) * (unsigned)sizeof(T) : ADN_DMA_OOB;
+        }
+    };
+    plan(p.s0);
 
     // copy of chunk `c` into image `buf`: NPIECE wave-instructions per thread
-    auto dma_chunk = [&](int c, int buf) {
+    auto dma_chunk = [&](int c, int buf, bool with_b = true) {
         if (c == p.nchunk0) {                          // wave-uniform: switch to the second source (virtual concat)
             hrs = src_rsrc(p.s1);
             hsoff = 0;
             cstr = (unsigned)((size_t)KG * p.s1.H * p.s1.W * ACT_BLOCK<T> * sizeof(T));
-#pragma unroll
-            for (int r = 0; r < A_ROUNDS; ++r) hcur[r] = hsec[r];
+            plan(p.s1);
         }
-        float *img = smem + (size_t)buf * SLOTS * 4;
 #pragma unroll
-        for (int k = 0; k < NPIECE; ++k) {
-            const int sb = k * NT + wave * 64;          // first slot of this wave-instruction (uniform)
-            if (sb >= SLOTS) continue;                   // tail of the last piece
-            float *dst = img + sb * 4;
-            if (k < A_ROUNDS && sb < A_SLOTS) dma16_buf(hrs, hcur[k < A_ROUNDS ? k : 0], hsoff, dst);
-            else dma16_buf(wrs, loff, wsoff + (unsigned)(sb - A_SLOTS) * 16u, dst);
-        }
+        for (int k = 0; k < NPIECE; ++k) dma_piece(k, buf, true, with_b);
         hsoff += cstr;
         wsoff += B_DW * 4;
     };
@@ -591,7 +608,7 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void conv_dma(const ConvArgs p)
     const int a_lane = ((wm * MB * 2 + ((lane >> 4) & 1)) * RSLOT + (lane & 15) * PSLOT) * 4 + hh * 4;
     const int b_lane = A_SLOTS * 4 + hh * BN * 4 + (wn * NB * 32 + l31) * 4;
 
-    dma_chunk(0, 0);
+    dma_chunk(0, 0, false);                            // halo of chunk 0 (its weight slab went out before the plan)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int c = 0; c < p.nchunk; ++c) {
@@ -796,6 +813,14 @@ hipError_t launch_dma_cfg(const ConvArgs &a, hipStream_t st)
     using C = DmaCfg<T, TH, BN, WM, WN, TAPS, KG>;
     const long nwg = (long)a.N * a.tilesY * a.tilesX * a.nct;
     if (nwg <= 0 || nwg > 0x7fffffffL) return hipErrorInvalidValue;
+    ConvArgs a2 = a;                                    // reciprocals of the tile decode's divisors (fdGc = nct; fdGc.d = 0: plain division)
+    a2.fdGc = a2.fdNcg = a2.fdTx = a2.fdTy = FastDiv{0u, 0u};
+    const long maxd = a.nct > a.tilesX ? (a.nct > a.tilesY ? a.nct : a.tilesY) : (a.tilesX > a.tilesY ? a.tilesX : a.tilesY);
+    if ((unsigned long long)nwg * (unsigned long long)maxd < 0x100000000ull) {
+        a2.fdGc = make_fastdiv((unsigned)a.nct);
+        a2.fdTx = make_fastdiv((unsigned)a.tilesX);
+        a2.fdTy = make_fastdiv((unsigned)a.tilesY);
+    }
     auto kern = conv_dma<T, TH, BN, WM, WN, TAPS, KG, EPI, WPE>;
     if (C::LDS_BYTES > 64 * 1024) {
         // the attribute is per device: remember which devices of this process have it
@@ -810,7 +835,7 @@ hipError_t launch_dma_cfg(const ConvArgs &a, hipStream_t st)
             attr_mask.fetch_or(bit, std::memory_order_release);
         }
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(C::NT), C::LDS_BYTES, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(C::NT), C::LDS_BYTES, st, a2);
     return hipGetLastError();
 }
 

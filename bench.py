@@ -274,8 +274,10 @@ def bench_stft(dev, clips=10000, length=132300, n_fft=1024, hop=256, steps=20, w
     res["fused_to_network_input"] = {
         "what": f"adn_stft_mag_fit: the same clips -> ({clips},1,{F_BINS},{T_FRAMES}) = STFT + fp16 round trip + crop "
                 "(data_loader.py:41-42,54-72) in one kernel, bit-identical to adn_stft_mag + adn_quantize_pad",
+        "kernel": "stft_fit_kernel<512,4,3>: persistent workgroups, 32-frame groups = whole 128-byte output lines, fp16 [bin][frame] image",
         "ms_per_launch": round(ms_fit, 4), "clips_per_s": round(clips / (ms_fit * 1e-3), 1),
-        "algorithmic_GBps": round(fit_bytes / (ms_fit * 1e-3) / 1e9, 1)}
+        "algorithmic_bytes_per_launch": fit_bytes,
+        "algorithmic_GBps": round(fit_bytes / (ms_fit * 1e-3) / 1e9, 1), "frac_hbm_peak": round(fit_bytes / (ms_fit * 1e-3) / 1e9 / 8000.0, 4)}
     del fit
     if cpu_clips > 0:
         import oracle
@@ -518,6 +520,9 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the sub-benchmarks (stft = configs[2], f16 = configs[4], fp32_b256, b1)")
+    ap.add_argument("--extras", default="stft,f16,fp32_b256,b1",
+                    help="which sub-benchmarks to run (comma list; tools/profile_bench.sh profiles with stft,f16 only, so that the "
+                         "kernel statistics of the headline kernel are not mixed with other batch sizes)")
     ap.add_argument("--stft-steps", type=int, default=20)
     ap.add_argument("--f16-steps", type=int, default=10)
     ap.add_argument("--b256-steps", type=int, default=10)
@@ -537,10 +542,13 @@ def main() -> None:
         raise SystemExit("bench.py needs a ROCm device (no CPU path)")
     if args.steps < 1 or args.steps > 4096:
         raise SystemExit("--steps must be in [1, 4096]")
-    rank, local_rank, world = D.init_from_env("nccl")
+    # ADN_BENCH_REHEARSAL=1 (one-GPU boxes only): the N > 1 code path with every rank on device 0 and gloo moving the CUDA
+    # tensors -- rehearses the driver's torch.distributed.run command line where no second GPU exists; never a measurement
+    rehearsal = os.environ.get("ADN_BENCH_REHEARSAL", "") not in ("", "0")
+    rank, local_rank, world = D.init_from_env("gloo" if rehearsal else "nccl")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", (local_rank % torch.cuda.device_count() if rehearsal else local_rank) if world > 1 else 0)
     torch.cuda.set_device(dev)
 
     sd_np = make_state_dict(1234)                                     # replicated weights, regenerated per rank
@@ -575,6 +583,8 @@ def main() -> None:
                             {"lib_digest": lib_digest()[:12]})
         out["roofline"] = conv_roofline(ms_mean, b, algo, peak, kname, tkey, wmode)
         out["forward"] = forward_summary(ms_mean, b, algo, peak, wmode)
+        if rehearsal:
+            out["data"] = "synthetic; REHEARSAL of the N > 1 path on one GPU (gloo, every rank on device 0): not a measurement"
         if world > 1:
             out["config"]["compare_with"] = ("the N = 1 line's fp32_b256.value (the same 256 clips per GPU on one GPU); the N = 1 "
                                              "headline value is BASELINE configs[1] at 64 clips")
@@ -583,11 +593,16 @@ def main() -> None:
             net._workspace = None
             del x, target
             torch.cuda.empty_cache()
-            out["stft"] = bench_stft(dev, steps=args.stft_steps, cpu_clips=0 if args.no_stft_cpu else 4096)
+            extras = {e.strip() for e in args.extras.split(",") if e.strip()}
+            if "stft" in extras:
+                out["stft"] = bench_stft(dev, steps=args.stft_steps, cpu_clips=0 if args.no_stft_cpu else 4096)
             if not f16:
-                out["f16"] = bench_f16(sd_np, dev, steps=args.f16_steps)
-                out["fp32_b256"] = bench_fp32_b256(sd_np, dev, steps=args.b256_steps)
-                out["b1"] = bench_latency(sd_np, dev)
+                if "f16" in extras:
+                    out["f16"] = bench_f16(sd_np, dev, steps=args.f16_steps)
+                if "fp32_b256" in extras:
+                    out["fp32_b256"] = bench_fp32_b256(sd_np, dev, steps=args.b256_steps)
+                if "b1" in extras:
+                    out["b1"] = bench_latency(sd_np, dev)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(sd_np)
         print(json.dumps(out), flush=True)

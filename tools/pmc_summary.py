@@ -33,6 +33,7 @@ FAMILIES = {
     "convt_f16": lambda n: n.startswith(("conv_mfma<_Float16", "conv_dma<_Float16")) and ", 1, 4, 2" in n,
     "stft_wave_kernel": lambda n: n.startswith("stft_wave_kernel") and not n.rstrip().endswith("true>"),
     "stft_wave_kernel_fit": lambda n: n.startswith("stft_wave_kernel") and n.rstrip().endswith("true>"),
+    "stft_fit_kernel": lambda n: n.startswith("stft_fit_kernel"),
     "conv_first_kernel": lambda n: n.startswith(("conv_first_kernel<float", "conv_first_c8_kernel")),
     "conv_out_kernel": lambda n: n.startswith("conv_out_kernel<float"),
     "conv_first_kernel_f16": lambda n: n.startswith("conv_first_kernel<_Float16"),
