@@ -92,6 +92,10 @@ struct adn_unet {
     // Off by default: it changes the summation order, and the default path keeps a clip's result bit-identical
     // whatever batch it is computed in.
     bool allow_split = false;
+    // fp32 transposed convolutions on the bf16 matrix cores through a three-term split of both operands (six products, fp32
+    // accumulation; conv_dma<..., SPLIT>): fp32-level accuracy at 3/8 of the exact-fp32 matrix time.  ADN_CONVT_SPLIT=0 when the
+    // handle is created keeps the exact-fp32 MFMA form.
+    bool convt_split = true;
     size_t zeros_off = 0;          // 64 zero floats inside the packed buffer
 };
 
@@ -226,6 +230,48 @@ void pack_convt(const float *w /*(Cin,Cout,2,2)*/, int Cin, int Cout, T *dst)
                     }
 }
 
+// The same GEMM for the split-bf16 form of conv_dma (fp32 path; conv_kernels.hip, SPLIT): every weight is written as three bf16
+// terms w = hi + mid + lo (round-to-nearest-even each, 24 mantissa bits in all), one plane per term:
+// [column tile][chunk of 16 channels][plane][half h][column n][8 bf16], element kk of half h = input channel chunk*16 + 8h + kk.
+inline uint16_t bf16_rne(float f)
+{
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+inline float bf16_to_float(uint16_t b)
+{
+    const uint32_t u = (uint32_t)b << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+void pack_convt_split(const float *w /*(Cin,Cout,2,2)*/, int Cin, int Cout, uint16_t *dst)
+{
+    const int BN = 128, KC = 16;
+    const int ncol = 4 * Cout, nct = ncol / BN, nchunk = Cin / KC;
+    size_t o = 0;
+    for (int ct = 0; ct < nct; ++ct)
+        for (int ch = 0; ch < nchunk; ++ch)
+            for (int plane = 0; plane < 3; ++plane)
+                for (int h = 0; h < 2; ++h)
+                    for (int n = 0; n < BN; ++n) {
+                        int ij, co;
+                        convt_column_host(ct * BN + n, Cout, ij, co);
+                        for (int kk = 0; kk < 8; ++kk) {
+                            const int ci = ch * KC + 8 * h + kk;
+                            const float v = w[((size_t)ci * Cout + co) * 4 + ij];
+                            const uint16_t hi = bf16_rne(v);
+                            const float r1 = v - bf16_to_float(hi);
+                            const uint16_t mid = bf16_rne(r1);
+                            const float r2 = r1 - bf16_to_float(mid);
+                            dst[o++] = plane == 0 ? hi : plane == 1 ? mid : bf16_rne(r2);
+                        }
+                    }
+}
+
 struct Plan {
     int N, H[5], W[5];
     size_t tA, tB, skip[4], pool[4], part, total;   // BYTE offsets into the workspace (part: split-K partial sums)
@@ -318,6 +364,8 @@ adn::ConvArgs conv_args(const adn_unet *h, const Conv3x3Layer &L, adn::ConvKind 
     a.dot_bias = 0.f;
     a.firstw = nullptr;
     a.firstb = nullptr;
+    a.split = 0;
+    a.nwg_total = 0;
     return a;
 }
 
@@ -460,6 +508,8 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
         t.dot_bias = 0.f;
         t.firstw = nullptr;
         t.firstb = nullptr;
+        t.split = h->convt_split ? 1 : 0;
+        t.nwg_total = 0;
         ADN_MARK();
         ADN_HIP(adn::launch_conv_mfma(adn::CONVT2X2, t, f16, st));
         // first conv of the DoubleConv reads cat([skip, x1]) virtually
@@ -564,6 +614,8 @@ int adn_unet_create_ex(adn_unet **handle, int device, const float *const *t, int
         h->use_wino = std::strcmp(algo, "direct") != 0;
     if (h->f16) h->use_wino = false;                           // the fp16 path runs the direct fp16-MFMA kernels
     if (const char *sk = std::getenv("ADN_WINO_SPLITK")) h->allow_split = std::atoi(sk) != 0;
+    if (const char *cs = std::getenv("ADN_CONVT_SPLIT")) h->convt_split = std::atoi(cs) != 0;
+    if (h->f16) h->convt_split = false;
     if (const char *wt = std::getenv("ADN_WINO_TILE")) {
         h->use_wino4 = std::atoi(wt) != 2;
         h->force_wino4 = std::atoi(wt) == 4;
@@ -628,6 +680,9 @@ int adn_unet_create_ex(adn_unet **handle, int device, const float *const *t, int
         if (h->f16) {
             TL.w_off = reserve(((size_t)4 * cin * co + 1) / 2);
             pack_convt<_Float16>(t[ti], cin, co, reinterpret_cast<_Float16 *>(host.data() + TL.w_off));
+        } else if (h->convt_split) {
+            TL.w_off = reserve(((size_t)3 * 4 * cin * co + 1) / 2);          // three bf16 planes
+            pack_convt_split(t[ti], cin, co, reinterpret_cast<uint16_t *>(host.data() + TL.w_off));
         } else {
             TL.w_off = reserve((size_t)4 * cin * co);
             pack_convt<float>(t[ti], cin, co, host.data() + TL.w_off);

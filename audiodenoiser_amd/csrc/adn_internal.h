@@ -74,6 +74,8 @@ struct ConvArgs {
     int pair;              // wino4_conv_f32 only: 1 = a workgroup tile holds two clips side by side (images <= 16 px wide)
     FastDiv fdGc, fdNcg, fdTx, fdTy;   // wino4_conv_f32 only: the divisors of its tile decode (fdGc.d == 0: plain division)
     int nwg_total;         // wino4_conv_f32 only: logical workgroup ids (= tiles incl. supertile padding) of the launch
+    int split;             // fp32 transposed convolution only: 1 = weights are three bf16 planes (pack_convt_split), the contraction
+                           // runs as six bf16 MFMA products per term pair with fp32 accumulation (conv_dma<..., SPLIT>)
     int ablate;            // timing experiments only (ADN_WINO_ABLATE); 0 in production
     const float *zeros;    // >= 16 bytes of zeros in device memory (source of padding lanes of the LDS-DMA copy)
     void *dbg;             // diagnostic stamp buffer (ADN_WINO_STAMP); nullptr in production

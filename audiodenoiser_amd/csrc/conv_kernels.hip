@@ -477,7 +477,7 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs &p, f32x16 (
 //               The A part is padded to a multiple of 64 slots so that every wave-instruction is wholly A or wholly B.
 //     B (weights): the packed slab of the chunk, a linear copy.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int TH, int BN, int WM, int WN, int TAPS, int KG>
+template <typename T, int TH, int BN, int WM, int WN, int TAPS, int KG, int SPLIT = 0>
 struct DmaCfg {
     static constexpr int NT = 64 * WM * WN;
     static constexpr int HALO = (TAPS == 9) ? 1 : 0;
@@ -487,7 +487,8 @@ struct DmaCfg {
     static constexpr int RSLOT = PW * PSLOT + ((KG == 1) ? 1 : 0);     // slots per halo row
     static constexpr int A_USED = PH * RSLOT;
     static constexpr int A_SLOTS = (A_USED + 63) / 64 * 64;
-    static constexpr int B_SLOTS = TAPS * KG * 2 * BN;
+    // SPLIT (fp32 activations, bf16 matrix cores; conv_dma below): three bf16 planes (hi, mid, lo) of one 16-channel k-group
+    static constexpr int B_SLOTS = SPLIT ? TAPS * 3 * 2 * BN : TAPS * KG * 2 * BN;
     static constexpr int SLOTS = A_SLOTS + B_SLOTS;                    // per image
     static constexpr int NPIECE = (SLOTS + NT - 1) / NT;               // wave-instructions per thread and chunk
     static constexpr int A_ROUNDS = (A_SLOTS + NT - 1) / NT;           // of which may carry halo slots
@@ -495,10 +496,35 @@ struct DmaCfg {
     static_assert(B_SLOTS % 64 == 0, "weight slab must be a whole number of wave copies");
 };
 
-template <typename T, int TH, int BN, int WM, int WN, int TAPS, int KG, int EPI, int WPE>
+// SPLIT = 1 (fp32 storage only; the transposed convolutions): the contraction runs on the BF16 matrix cores (16x the exact-fp32
+// MFMA rate) without giving up fp32 accuracy.  Every fp32 operand is split into three bf16 terms, x = hi + mid + lo (24 mantissa
+// bits; bf16 has fp32's exponent range, so nothing needs scaling and nothing can overflow), and the six products of total order
+// <= 2 -- hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid -- are accumulated in fp32 (the dropped terms are <= 2^-24 relative): the
+// result differs from an exact-fp32 MFMA sum by rounding noise (measured through the network: tools/report_parity.py).  Weights
+// are split on the host (pack_convt_split, adn_api.hip: three planes per 16-channel chunk), activations in registers after the LDS
+// read (v_cvt_pk_bf16_f32 + a subtraction per term).  6 x v_mfma_f32_32x32x16_bf16 (192 cycles) replace 8 x v_mfma_f32_32x32x2_f32
+// (512 cycles) per 32x32 tile and 16 channels.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split3_bf16(const f32x4 &x0, const f32x4 &x1, bf16x8 &hi, bf16x8 &mid, bf16x8 &lo)
+{
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = e < 4 ? x0[e] : x1[e - 4];
+        const __bf16 h = (__bf16)x;
+        const float r1 = x - (float)h;
+        const __bf16 m = (__bf16)r1;
+        const float r2 = r1 - (float)m;
+        hi[e] = h;
+        mid[e] = m;
+        lo[e] = (__bf16)r2;
+    }
+}
+
+template <typename T, int TH, int BN, int WM, int WN, int TAPS, int KG, int EPI, int WPE, int SPLIT = 0>
 __global__ __launch_bounds__(64 * WM * WN, WPE) void conv_dma(const ConvArgs p)
 {
-    using C = DmaCfg<T, TH, BN, WM, WN, TAPS, KG>;
+    using C = DmaCfg<T, TH, BN, WM, WN, TAPS, KG, SPLIT>;
+    static_assert(!SPLIT || (sizeof(T) == 4 && KG == 2 && TAPS == 1), "SPLIT: fp32 storage, one 16-channel chunk (two fp32 k-groups), 1 tap");
     constexpr int NT = C::NT, EPV = Elem<T>::EPV, HALO = C::HALO, PW = C::PW;
     static_assert(2 * EPV == ACT_BLOCK<T>, "one k-group = one channel block of the activation layout");   // KG blocks per chunk
     constexpr int PSLOT = C::PSLOT, RSLOT = C::RSLOT, A_SLOTS = C::A_SLOTS, SLOTS = C::SLOTS, NPIECE = C::NPIECE;
@@ -614,6 +640,33 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void conv_dma(const ConvArgs p)
     for (int c = 0; c < p.nchunk; ++c) {
         if (c + 1 < p.nchunk) dma_chunk(c + 1, (c + 1) & 1);          // lands under the MFMAs below
         const float *img = smem + (size_t)(c & 1) * SLOTS * 4;
+        if constexpr (SPLIT) {
+            // lane (row l31, half hh) holds channels 8 hh .. 8 hh + 7 of its pixel = k-group hh of the chunk (two 16-byte slots)
+            bf16x8 ah[MB], am[MB], al[MB];
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+                const float *ap = img + a_lane + (i * 2 * RSLOT) * 4 + hh * 4;          // a_lane carries hh * 4: + hh * 4 more = k-group hh
+                split3_bf16(*reinterpret_cast<const f32x4 *>(ap), *reinterpret_cast<const f32x4 *>(ap + 4), ah[i], am[i], al[i]);
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                // three bf16 planes packed on the host.  (Splitting fp32 weights in registers instead -- 16 instead of 20 KB staged per
+                // chunk, four workgroups per CU -- measured 0.725 / 0.726 / 0.751 / 0.835 ms for up1..up4 against 0.646 / 0.655 / 0.701 /
+                // 0.879 ms: better only for the 8-chunk layer; not kept.)
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(img + b_lane + j * 128));
+                const bf16x8 bm = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(img + b_lane + j * 128 + 2 * BN * 4));
+                const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(img + b_lane + j * 128 + 4 * BN * 4));
+#pragma unroll
+                for (int i = 0; i < MB; ++i) {           // small terms first, the leading product last
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bm, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
+                }
+            }
+        } else
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             const int dy = (TAPS == 9) ? tap / 3 : 0, dx = (TAPS == 9) ? tap % 3 : 0;
@@ -807,10 +860,10 @@ hipError_t launch_cfg(const ConvArgs &a, hipStream_t st)
     return hipGetLastError();
 }
 
-template <typename T, int TH, int BN, int WM, int WN, int TAPS, int KG, int EPI, int WPE>
+template <typename T, int TH, int BN, int WM, int WN, int TAPS, int KG, int EPI, int WPE, int SPLIT = 0>
 hipError_t launch_dma_cfg(const ConvArgs &a, hipStream_t st)
 {
-    using C = DmaCfg<T, TH, BN, WM, WN, TAPS, KG>;
+    using C = DmaCfg<T, TH, BN, WM, WN, TAPS, KG, SPLIT>;
     const long nwg = (long)a.N * a.tilesY * a.tilesX * a.nct;
     if (nwg <= 0 || nwg > 0x7fffffffL) return hipErrorInvalidValue;
     ConvArgs a2 = a;                                    // reciprocals of the tile decode's divisors (fdGc = nct; fdGc.d = 0: plain division)
@@ -821,7 +874,7 @@ hipError_t launch_dma_cfg(const ConvArgs &a, hipStream_t st)
         a2.fdTx = make_fastdiv((unsigned)a.tilesX);
         a2.fdTy = make_fastdiv((unsigned)a.tilesY);
     }
-    auto kern = conv_dma<T, TH, BN, WM, WN, TAPS, KG, EPI, WPE>;
+    auto kern = conv_dma<T, TH, BN, WM, WN, TAPS, KG, EPI, WPE, SPLIT>;
     if (C::LDS_BYTES > 64 * 1024) {
         // the attribute is per device: remember which devices of this process have it
         static std::atomic<unsigned long long> attr_mask{0};
@@ -881,6 +934,8 @@ hipError_t launch_conv_mfma_t(ConvKind kind, const ConvArgs &a, hipStream_t st)
 #ifdef ADN_EXPERIMENTS
             if (staging_regs()) return launch_cfg<T, 8, 128, 2, 2, 1, CONVT_KG, CONVT2X2>(a, st);
 #endif
+            // a.split: weights packed as three bf16 planes (pack_convt_split): the split-bf16 form on the bf16 matrix cores
+            if (a.split) return launch_dma_cfg<T, 8, 128, 2, 2, 1, CONVT_KG, CONVT2X2, 3, 1>(a, st);
             return launch_dma_cfg<T, 8, 128, 2, 2, 1, CONVT_KG, CONVT2X2, CONVT_WPE>(a, st);
         }
         if (a.Cout == 64) {

@@ -200,22 +200,51 @@ def conv_roofline(ms_mean, b, algo, peak, kernel_name, traffic_key, wino_mode="a
     return out
 
 
+def convt_uses_split_bf16(f16: bool) -> bool:
+    """fp32 transposed convolutions run on the bf16 matrix cores through a three-term split of both operands (six products, fp32
+    accumulation; conv_dma<..., SPLIT>) unless ADN_CONVT_SPLIT=0 was set when the handle was created."""
+    return (not f16) and os.environ.get("ADN_CONVT_SPLIT", "1") != "0"
+
+
 def forward_summary(ms_mean, b, algo, peak, wino_mode="auto"):
-    from audiodenoiser_amd.roofline import PEAK_HBM_GBS, executed_mfma_flops, unet_launches
+    """All 23 launches.  `executed_mfma_tflops` / `frac_mfma_peak_executed` cover the launches that run on the matrix pipe `peak`
+    belongs to (fp32 path: the 3x3 layers, and the transposed convolutions only when they run the exact-fp32 form); the
+    split-bf16 transposed convolutions are summarised under `convt` against the bf16 peak."""
+    from audiodenoiser_amd.roofline import PEAK_HBM_GBS, PEAK_MFMA_F16_TFLOPS, executed_mfma_flops, unet_launches
     launches = unet_launches(F_BINS, T_FRAMES)
-    half = 0.5 if algo == "direct_f16" else 1.0
+    f16 = algo == "direct_f16"
+    half = 0.5 if f16 else 1.0
+    split = convt_uses_split_bf16(f16)
     fwd_ms = float(ms_mean.sum())
     tot_flops = sum(l["flops"] for l in launches) * b
-    tot_exec = sum(executed_mfma_flops(l, algo if l["kind"] == "conv3x3" else ("direct_f16" if half < 1 else "direct"),
-                                       wino_mode) for l in launches) * b
+    on_pipe = [i for i, l in enumerate(launches) if l["kind"] == "conv3x3" or (l["kind"] == "convt" and not split)]
+    pipe_exec = sum(executed_mfma_flops(launches[i], algo if launches[i]["kind"] == "conv3x3" else ("direct_f16" if f16 else "direct"),
+                                        wino_mode) for i in on_pipe) * b
+    pipe_ms = float(ms_mean[on_pipe].sum())
     tot_bytes = (sum(l["act_bytes"] for l in launches) * b + sum(l["weight_bytes"] for l in launches)) * half
-    return {"kernel_ms": round(fwd_ms, 3),
-            "algorithmic_tflops": round(tot_flops / (fwd_ms * 1e-3) / 1e12, 2),
-            "executed_mfma_tflops": round(tot_exec / (fwd_ms * 1e-3) / 1e12, 2),
-            "frac_mfma_peak_executed": round(tot_exec / (fwd_ms * 1e-3) / 1e12 / peak, 4),
-            "algorithmic_GBps": round(tot_bytes / (fwd_ms * 1e-3) / 1e9, 1),
-            "frac_hbm_peak": round(tot_bytes / (fwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-            "per_launch_ms": {l["name"]: round(float(m), 4) for l, m in zip(launches, ms_mean)}}
+    out = {"kernel_ms": round(fwd_ms, 3),
+           "algorithmic_tflops": round(tot_flops / (fwd_ms * 1e-3) / 1e12, 2),
+           "executed_mfma_tflops": round(pipe_exec / (pipe_ms * 1e-3) / 1e12, 2),
+           "frac_mfma_peak_executed": round(pipe_exec / (pipe_ms * 1e-3) / 1e12 / peak, 4),
+           "executed_mfma_basis": f"{len(on_pipe)} launches on this matrix pipe, {round(pipe_ms, 3)} ms of the forward",
+           "algorithmic_GBps": round(tot_bytes / (fwd_ms * 1e-3) / 1e9, 1),
+           "frac_hbm_peak": round(tot_bytes / (fwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+           "per_launch_ms": {l["name"]: round(float(m), 4) for l, m in zip(launches, ms_mean)}}
+    ct = [i for i, l in enumerate(launches) if l["kind"] == "convt"]
+    ct_ms = float(ms_mean[ct].sum())
+    ct_alg = sum(launches[i]["flops"] for i in ct) * b
+    ct_bytes = sum(launches[i]["act_bytes"] * b + launches[i]["weight_bytes"] for i in ct) * half
+    out["convt"] = {"ms": round(ct_ms, 3), "algorithmic_tflops": round(ct_alg / (ct_ms * 1e-3) / 1e12, 2),
+                    "algorithmic_GBps": round(ct_bytes / (ct_ms * 1e-3) / 1e9, 1),
+                    "frac_hbm_peak": round(ct_bytes / (ct_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+    if split:
+        ct_exec = sum(executed_mfma_flops(launches[i], "direct") for i in ct) * b * 6.0
+        out["convt"].update({
+            "kernel": "conv_dma<float, 8, 128, 2, 2, 1, 2, CONVT, 3, SPLIT>: fp32 operands split into three bf16 terms, six "
+                      "v_mfma_f32_32x32x16_bf16 products per term pair, fp32 accumulation (fp32-level accuracy)",
+            "executed_bf16_mfma_tflops": round(ct_exec / (ct_ms * 1e-3) / 1e12, 2),
+            "frac_bf16_mfma_peak": round(ct_exec / (ct_ms * 1e-3) / 1e12 / PEAK_MFMA_F16_TFLOPS, 4)})
+    return out
 
 
 def bench_stft(dev, clips=10000, length=132300, n_fft=1024, hop=256, steps=20, warmup=3, cpu_clips=4096):

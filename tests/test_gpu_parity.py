@@ -588,6 +588,41 @@ def test_perceptual_loss_zero_and_errors(dev):
         perceptual_loss_per_clip(x[..., :31].contiguous(), x[..., :31].contiguous())     # T < 32: reflect pad 31 needs T > 31
 
 
+def test_convt_split_bf16_matches_exact_fp32_form(dev, weights_np, golden_dir, monkeypatch):
+    """The fp32 transposed convolutions run on the bf16 matrix cores through a three-term split of both operands (six products,
+    fp32 accumulation).  That is fp32-level arithmetic: against the exact-fp32 MFMA form (ADN_CONVT_SPLIT=0, read when a handle is
+    created) the whole network differs by rounding noise only -- a few 1e-7 of max|y| -- on even and odd shapes, and both forms sit
+    at the same distance from the reference golden."""
+    from audiodenoiser_amd.model import UNet
+    from audiodenoiser_amd.weights import make_input
+
+    def make():
+        m = UNet(1, 1)
+        m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in weights_np.items()}, strict=True)
+        return m.to(dev).eval()
+
+    split = make()
+    monkeypatch.setenv("ADN_CONVT_SPLIT", "0")
+    exact = make()
+    with torch.no_grad():
+        exact(torch.zeros((1, 1, 16, 16), device=dev))             # the handle (and its switch) is created at the first forward
+    monkeypatch.delenv("ADN_CONVT_SPLIT")
+    for (n, f, t) in ((2, 33, 47), (1, 257, 188), (1, 513, 256)):
+        x = torch.from_numpy(make_input(7, n, f, t)).to(dev)
+        g = np.load(os.path.join(golden_dir, f"unet_{f}x{t}.npz"))
+        with torch.no_grad():
+            ys, taps_s = split(x, return_taps=True)
+            ye, taps_e = exact(x, return_taps=True)
+        scale = float(ye.abs().max())
+        assert float((ys - ye).abs().max()) <= 2e-6 * scale, (f, t)
+        assert not torch.equal(ys, ye) or f < 64                # (different arithmetic: identical bits would mean the switch did nothing)
+        for name in ("up1", "up2", "up3", "up4"):
+            d = float((taps_s[name] - taps_e[name]).abs().max()) / float(taps_e[name].abs().max())
+            assert d <= 2e-6, (name, d)
+        es, ee = _rel(ys.cpu().numpy(), g["y"]), _rel(ye.cpu().numpy(), g["y"])
+        assert es <= TOL and ee <= TOL and es <= 2.0 * ee + 1e-6
+
+
 # ---------------------------------------------------------------------------------------------- fp16 path
 def test_fp16_path_within_1e2_of_fp32_reference(dev, weights_np, golden_dir):
     """BASELINE configs[4]: fp16 storage + fp16 MFMA (fp32 accumulate); outputs within 1e-2 (relative to max|ref|)

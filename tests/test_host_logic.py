@@ -452,6 +452,37 @@ def test_forward_shape_limits_are_reported():
     assert L.adn_unet_workspace_bytes(None, 1, 8192, 4000, ctypes.byref(need)) == 1
 
 
+def test_bf16_three_term_split_is_fp32_accurate():
+    """The arithmetic behind conv_dma<..., SPLIT> (fp32 transposed convolutions on the bf16 matrix cores): x = hi + mid + lo with
+    three round-to-nearest bf16 terms reconstructs an fp32 value to 2^-24, and the six products of order <= 2 summed in fp32 match
+    an fp32 dot product's accuracy (numpy restatement of pack_convt_split / split3_bf16; the GPU form is checked against the
+    exact-fp32 MFMA form in tests/test_gpu_parity.py::test_convt_split_bf16_matches_exact_fp32_form)."""
+    def bf16(x):                                             # round to nearest even, as v_cvt_pk_bf16_f32 / bf16_rne
+        u = x.astype(np.float32).view(np.uint32).astype(np.uint64)
+        u = (u + 0x7FFF + ((u >> 16) & 1)) >> 16 << 16
+        return u.astype(np.uint32).view(np.float32)
+
+    def split(x):
+        hi = bf16(x)
+        r1 = (x - hi).astype(np.float32)
+        mid = bf16(r1)
+        lo = bf16((r1 - mid).astype(np.float32))
+        return hi, mid, lo
+
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal(4096) * np.exp(rng.uniform(-20, 20, 4096))).astype(np.float32)      # 17 decades of magnitude
+    hi, mid, lo = split(x)
+    assert np.all(np.abs((hi.astype(np.float64) + mid + lo) - x) <= np.abs(x) * 2.0 ** -24)
+    a = np.maximum(rng.standard_normal((64, 1024)), 0).astype(np.float32) * 3
+    w = (rng.standard_normal((1024, 32)) * 0.02).astype(np.float32)
+    ref = a.astype(np.float64) @ w.astype(np.float64)
+    (ah, am, al), (wh, wm, wl) = split(a), split(w)
+    six = (al @ wh + ah @ wl + am @ wm + am @ wh + ah @ wm + ah @ wh).astype(np.float32)
+    m = np.abs(ref).max()
+    e_six, e_f32, e_one = np.abs(six - ref).max() / m, np.abs(a @ w - ref).max() / m, np.abs(ah @ wh - ref).max() / m
+    assert e_six <= 2e-6 and e_six <= 4 * e_f32 + 1e-7 and e_one > 1e-3        # one bf16 product alone is nowhere near
+
+
 def test_roofline_accounting():
     """bench.py's roofline inputs: SURVEY 8d totals, and executed matrix-core FLOPs (padded tiles counted)."""
     from audiodenoiser_amd.roofline import executed_mfma_flops, totals, unet_launches
