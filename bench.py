@@ -33,6 +33,7 @@ time for the K steps (min / max) and the all-gather's own time.
 
 Sub-benchmarks in the same JSON line (rank 0, N = 1 only; --no-extras skips them):
   `fp32_b256`  the main step at batch 256 (north_star's batch, one rank's shard of configs[3]).
+  `exact_f32`  the headline step with exact-fp32 matrix instructions everywhere (ADN_CONVT_SPLIT=0).
   `b1`    single-clip latency at 513x256 and the reference's own shapes (257x188 whole test set of 5 clips as test.py:112-113
           runs it, 256x64 at the training batch of 16), default kernels and the single-clip serving switches.
   `stft`  BASELINE configs[2]: 10 000 clips x 132 300 samples, n_fft 1024, hop 256, centred; HBM roofline of
@@ -494,6 +495,41 @@ def bench_fp32_b256(sd_np, dev, batch=256, steps=10, warmup=2):
     return res
 
 
+def bench_exact_f32(sd_np, dev, batch=64, steps=20, warmup=3):
+    """The headline step with exact-fp32 matrix instructions EVERYWHERE (ADN_CONVT_SPLIT=0 when the handle is created: the transposed
+    convolutions as v_mfma_f32_32x32x2_f32 GEMMs instead of the three-term bf16 split): the number to quote if the split -- an
+    fp32-accurate product formed on the bf16 matrix cores -- is not accepted as fp32 arithmetic."""
+    from audiodenoiser_amd.loss import perceptual_loss_per_clip
+    saved = os.environ.get("ADN_CONVT_SPLIT")
+    os.environ["ADN_CONVT_SPLIT"] = "0"
+    try:
+        net = make_net(sd_np, dev, "f32")
+        g = torch.Generator(device=dev).manual_seed(0)
+        x = torch.rand((batch, 1, F_BINS, T_FRAMES), generator=g, device=dev) * 4.0
+        target = torch.rand((batch, 1, F_BINS, T_FRAMES), generator=g, device=dev) * 4.0
+        with torch.no_grad():
+            for _ in range(warmup):
+                loss = perceptual_loss_per_clip(net(x), target)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                loss = perceptual_loss_per_clip(net(x), target)
+            torch.cuda.synchronize(dev)
+            el = time.perf_counter() - t0
+        assert bool(torch.isfinite(loss).all())
+        net._release()
+        del net, x, target
+        torch.cuda.empty_cache()
+    finally:
+        if saved is None:
+            os.environ.pop("ADN_CONVT_SPLIT", None)
+        else:
+            os.environ["ADN_CONVT_SPLIT"] = saved
+    return {"what": f"batch={batch} x 513x256, the same step with ADN_CONVT_SPLIT=0: every matrix instruction is an exact-fp32 MFMA",
+            "steps": steps, "warmup": warmup, "ms_per_step": round(el / steps * 1e3, 3),
+            "value": round(batch * T_FRAMES * steps / el, 1), "unit": "frames/s"}
+
+
 def bench_latency(sd_np, dev, iters=30):
     """Single-clip / small-batch latency: BASELINE configs[0] is one clip through the forward (test.py:112-113 runs its whole
     test set -- 5 clips of 257x188 -- as one batch; train.py:84 validates at batch 16 of 256x64).  Default kernels, and the
@@ -549,7 +585,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the sub-benchmarks (stft = configs[2], f16 = configs[4], fp32_b256, b1)")
-    ap.add_argument("--extras", default="stft,f16,fp32_b256,b1",
+    ap.add_argument("--extras", default="stft,f16,fp32_b256,b1,exact_f32",
                     help="which sub-benchmarks to run (comma list; tools/profile_bench.sh profiles with stft,f16 only, so that the "
                          "kernel statistics of the headline kernel are not mixed with other batch sizes)")
     ap.add_argument("--stft-steps", type=int, default=20)
@@ -608,8 +644,13 @@ def main() -> None:
 
     if rank == 0:
         algo, peak, kname, tkey, wmode = kernel_names(f16)
+        arith = ("fp16 storage + fp16 MFMA, fp32 accumulate" if f16 else
+                 "fp32 storage; 3x3 layers on exact-fp32 MFMA (Winograd F(4x4,3x3)); transposed convolutions "
+                 + ("with both fp32 operands split into three bf16 terms, six bf16-MFMA products, fp32 accumulate (fp32-accurate: "
+                    "whole-network parity 5.5e-6 of max|y| either way; `exact_f32` = the same step with exact-fp32 MFMA everywhere)"
+                    if convt_uses_split_bf16(False) else "on exact-fp32 MFMA (ADN_CONVT_SPLIT=0)"))
         out = assemble_line(elapsed, args.steps, args.warmup, world, b, args.dtype, tr["ranks"],
-                            {"lib_digest": lib_digest()[:12]})
+                            {"lib_digest": lib_digest()[:12], "arithmetic": arith})
         out["roofline"] = conv_roofline(ms_mean, b, algo, peak, kname, tkey, wmode)
         out["forward"] = forward_summary(ms_mean, b, algo, peak, wmode)
         if rehearsal:
@@ -632,6 +673,8 @@ def main() -> None:
                     out["fp32_b256"] = bench_fp32_b256(sd_np, dev, steps=args.b256_steps)
                 if "b1" in extras:
                     out["b1"] = bench_latency(sd_np, dev)
+                if "exact_f32" in extras and convt_uses_split_bf16(False):
+                    out["exact_f32"] = bench_exact_f32(sd_np, dev)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(sd_np)
         print(json.dumps(out), flush=True)
