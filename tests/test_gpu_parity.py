@@ -9,6 +9,7 @@ Nothing here reads /root/reference: goldens are committed under tests/golden/.
 """
 import ctypes
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -489,6 +490,33 @@ def test_stft_mag_fit_persistent_runs_many_clips(dev):
     b = torch.rand((3000, 24000), generator=g, device=dev) * 2 - 1
     f2 = stft_magnitude_fit(b, (256, 64), 512, 128, True)
     assert torch.equal(f2, quantize_pad_on_device(stft_magnitude(b, 512, 128, True), (256, 64)))
+
+
+def test_bench_two_rank_rehearsal_on_one_gpu(dev):
+    """The driver's N > 1 command line (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`) end to end with
+    two ranks, both on this GPU, gloo moving the CUDA tensors (ADN_BENCH_REHEARSAL=1: a rehearsal, not a measurement): the ranks
+    shard the clips, the per-clip values are gathered, rank 0 prints ONE JSON line that says how many ranks the collective held."""
+    import json
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ADN_BENCH_REHEARSAL="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch-per-gpu", "4"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["unit"] == "frames/s"
+    assert d["ranks"]["ranks_seen"] == 2 and d["ranks"]["rank_ids"] == [0, 1] and d["ranks"]["allgather_ms"] > 0
+    assert d["config"]["batch_per_gpu"] == 4 and d["config"]["global_batch"] == 8
+    assert abs(d["value"] - 8 * 256 * 2 / (d["ms_per_step"] * 2e-3)) <= 0.01 * d["value"]
+    assert "REHEARSAL" in d["data"] and "roofline" in d and "stft" not in d        # sub-benchmarks are N = 1 only
 
 
 def test_stft_rejects_bad_arguments(dev):
