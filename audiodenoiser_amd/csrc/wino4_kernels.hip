@@ -86,6 +86,9 @@ constexpr int KC = 8;                        // input channels per chunk
 #ifndef W4_FASTDIV                            // 1: tile decode by multiply-high with launch constants instead of seven software divisions
 #define W4_FASTDIV 1
 #endif
+#ifndef W4_EPI_PK                             // output transform on register pairs in packed fp32: 1 = pooling variant, 2 = plain variant too
+#define W4_EPI_PK 1
+#endif
 #ifndef W4_BIAS_ACC                           // 1: the bias rides in the accumulator of transform-domain position (1, 1) (below): -0.8 %
 #define W4_BIAS_ACC 1
 #endif
@@ -171,6 +174,19 @@ __device__ __forceinline__ void at6(float m0, float m1, float m2, float m3, floa
     y3 = __builtin_fmaf(8.f, d, b) + m5;
 }
 
+// The same for two accumulator registers at once (packed fp32: the epilogue runs no MFMAs beside it; operation for operation the
+// arithmetic of at6, so results are bit-identical)
+__device__ __forceinline__ f32x2 pk_fma(float c, f32x2 a, f32x2 b) { return __builtin_elementwise_fma(f32x2{c, c}, a, b); }
+__device__ __forceinline__ void at6x2(f32x2 m0, f32x2 m1, f32x2 m2, f32x2 m3, f32x2 m4, f32x2 m5, f32x2 &y0, f32x2 &y1, f32x2 &y2,
+                                      f32x2 &y3)
+{
+    const f32x2 a = m1 + m2, b = m1 - m2, c = m3 + m4, d = m3 - m4;
+    y0 = m0 + a + c;
+    y1 = pk_fma(2.f, d, b);
+    y2 = pk_fma(4.f, c, a);
+    y3 = pk_fma(8.f, d, b) + m5;
+}
+
 // lane id without the work-item-id register: values derived from threadIdx.x would otherwise have to survive the K loop
 // (in registers the loop needs, i.e. as scratch spills: measured 0.3 GB of spill traffic per full-resolution launch)
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
@@ -246,7 +262,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #ifdef ADN_EXPERIMENTS
     // workgroup timeline (ADN_W4_TIMELINE, p.dbg != nullptr): clock at entry / first chunk ready / loop done / stores issued /
     // stores drained + the hardware id of the CU, written by wave 0; launch_wino4_conv prints the per-CU averages
-    const unsigned long long tl0 = __builtin_amdgcn_s_memtime();
+    unsigned long long tl0 = __builtin_amdgcn_s_memtime();
     unsigned long long tl1 = 0, tl2 = 0, tla = 0, tlb = 0, tlc = 0;
 #endif
     const int tid = threadIdx.x;
@@ -274,6 +290,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     for (int lid = lstart + (int)(blockIdx.x >> 3); lid < lend; lid += lstep) {
     asm volatile("" : "+s"(pa));                          // (opaque per tile: nothing loaded through it is hoisted out of the loop)
     KArgs &p = *pa;
+#ifdef ADN_EXPERIMENTS
+    tl0 = __builtin_amdgcn_s_memtime();                   // (timeline: one record per tile)
+#endif
     do {
 #else
     const int lid = xcd_remap4(blockIdx.x, gridDim.x);
@@ -728,13 +747,53 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             }
         }
     };
+    // W4_EPI_PK: the pooling variant runs the output transform on register PAIRS (r, r + 1) in packed fp32 (half the vector
+    // instructions); exchange piece (rp, a, bp) = {y[a][2bp] of r, r+1, y[a][2bp+1] of r, r+1}.  Measured per batch-64 step
+    // (profiles/r03_wino4_variants.txt, call r03q): pooling layers -0.5...-1.1 %, plain layers +0.2...0.4 % (so: pooling only).
+    constexpr bool PK = W4_EPI_PK && !SWP && (EPI == CONV3X3_RELU_POOL || (W4_EPI_PK == 2 && EPI == CONV3X3_RELU));
+    auto partial2 = [&](const f32x4 *m, int rp, f32x2 (&y)[4][4]) {
+        auto pr = [&](int pos) { return rp ? f32x2{m[pos][2], m[pos][3]} : f32x2{m[pos][0], m[pos][1]}; };
+        f32x2 w[4][3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+            at6x2(pr(0 * 3 + b), pr(1 * 3 + b), pr(2 * 3 + b), pr(3 * 3 + b), pr(4 * 3 + b), pr(5 * 3 + b), w[0][b], w[1][b], w[2][b], w[3][b]);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            if (jh == 0) {
+                const f32x2 s = w[a][1] + w[a][2], t = w[a][1] - w[a][2];
+                y[a][0] = w[a][0] + s;
+                y[a][1] = t;
+                y[a][2] = s;
+                y[a][3] = t;
+            } else {
+                const f32x2 s = w[a][0] + w[a][1], t = w[a][0] - w[a][1];
+                y[a][0] = s;
+                y[a][1] = t + t;                          // (= 2 t exactly)
+                y[a][2] = s * f32x2{4.f, 4.f};
+                y[a][3] = pk_fma(8.f, t, w[a][2]);
+            }
+        }
+    };
     float *xb = smem + ((tb * 2 + jh) * 16 * 64 + el) * 4;           // this wave's outgoing block [16 pieces][64 lanes][4]
+    if constexpr (PK) {
+#pragma unroll
+        for (int rp = 0; rp < 2; ++rp) {
+            f32x2 y[4][4];
+            partial2(acc[1], rp, y);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int bp = 0; bp < 2; ++bp)
+                    *reinterpret_cast<f32x4 *>(xb + ((rp * 4 + a) * 2 + bp) * 256) = f32x4{y[a][2 * bp][0], y[a][2 * bp][1], y[a][2 * bp + 1][0], y[a][2 * bp + 1][1]};
+        }
+    } else {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         float y[4][4];
         partial(acc[1], r, y);
 #pragma unroll
         for (int a = 0; a < 4; ++a) *reinterpret_cast<f32x4 *>(xb + (r * 4 + a) * 256) = f32x4{y[a][0], y[a][1], y[a][2], y[a][3]};
+    }
     }
     __syncthreads();
     const float *xr = smem + ((tb * 2 + (jh ^ 1)) * 16 * 64 + el) * 4;  // the partner's block: its sum for OUR cout block
@@ -862,6 +921,54 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 for (int a = 0; a < 2; ++a) prow[a] = pb + ((size_t)((gy0e >> 1) + a) * Wp + (gx0e >> 1)) * 8;
             }
         }
+        if constexpr (PK) {
+#pragma unroll
+        for (int rp = 0; rp < 2; ++rp) {
+            f32x2 y[4][4];
+            partial2(acc[0], rp, y);
+            const int gy = gy0e, gx = gx0e + 8 * rp;     // .x: tile column 2 rp (pixels gx + b), .y: tile column 2 rp + 1 (gx + 4 + b)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+#pragma unroll
+                for (int bp = 0; bp < 2; ++bp) {
+                    const f32x4 o = *reinterpret_cast<const f32x4 *>(xr + ((rp * 4 + a) * 2 + bp) * 256);
+                    y[a][2 * bp] = __builtin_elementwise_max(y[a][2 * bp] + f32x2{o[0], o[1]}, f32x2{0.f, 0.f});
+                    y[a][2 * bp + 1] = __builtin_elementwise_max(y[a][2 * bp + 1] + f32x2{o[2], o[3]}, f32x2{0.f, 0.f});
+                }
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const float v = y[a][b][e];
+                        if constexpr (INT) {
+                            if (!(ABL & 4096) || v == 123.456f) orow[a][(8 * rp + 4 * e + b) * 8] = v;
+                        } else {
+                            if (clip_ok && gy + a < p.H && gx + 4 * e + b < p.W && (!(ABL & 4096) || v == 123.456f))
+                                ob[((size_t)(gy + a) * p.W + gx + 4 * e + b) * 8] = v;
+                        }
+                    }
+            }
+            if (EPI == CONV3X3_RELU_POOL) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const f32x2 mx2 = __builtin_elementwise_max(__builtin_elementwise_max(y[2 * a][2 * b], y[2 * a][2 * b + 1]),
+                                                                    __builtin_elementwise_max(y[2 * a + 1][2 * b], y[2 * a + 1][2 * b + 1]));
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const float mx = mx2[e];
+                            if constexpr (INT) {
+                                if (!(ABL & 4096) || mx == 123.456f) prow[a][(4 * rp + 2 * e + b) * 8] = mx;
+                            } else {
+                                const int py = (gy >> 1) + a, px = (gx >> 1) + 2 * e + b;
+                                if (clip_ok && py < Hp && px < Wp && (!(ABL & 4096) || mx == 123.456f)) pb[((size_t)py * Wp + px) * 8] = mx;
+                            }
+                        }
+                    }
+            }
+        }
+        } else
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float y[4][4];
@@ -900,27 +1007,34 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if (interior) finish(std::true_type{});
     else finish(std::false_type{});
     }   // !SWP
+#ifdef ADN_EXPERIMENTS
+#define W4_DBG_WRITE(rec)                                                                                          \
+    if (p_.dbg && wave == 0) {                                                                                     \
+        const unsigned long long tl3 = __builtin_amdgcn_s_memtime();                                               \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                           \
+        const unsigned long long tl4 = __builtin_amdgcn_s_memtime();                                               \
+        const unsigned hwid = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));        /* HW_REG_HW_ID */ \
+        const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));        /* HW_REG_XCC_ID */ \
+        if (lane == 0) {                                                                                           \
+            unsigned long long *o = reinterpret_cast<unsigned long long *>(p_.dbg) + (size_t)(rec) * 8;            \
+            o[0] = tl0; o[1] = tl1; o[2] = tl2; o[3] = tl3; o[4] = tl4; o[5] = ((unsigned long long)xcc << 32) | hwid; \
+            o[6] = ((tla - tl0) << 32) | ((tlb - tla) & 0xffffffffull); o[7] = tlc - tlb;                          \
+        }                                                                                                          \
+    }
+#else
+#define W4_DBG_WRITE(rec)
+#endif
 #if W4_PERSIST
     } while (0);
     // every wave has read its partner's exchange block (and the fused-1x1 table): the images may be refilled.  The stores of
     // this tile are still draining; the next tile's first wait (vmcnt(0) in front of its first barrier) covers them.
     __syncthreads();
+    W4_DBG_WRITE(lid)
     }   // tiles of this workgroup
+#else
+    W4_DBG_WRITE(blockIdx.x)
 #endif
-#ifdef ADN_EXPERIMENTS
-    if (p_.dbg && wave == 0) {
-        const unsigned long long tl3 = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned long long tl4 = __builtin_amdgcn_s_memtime();
-        const unsigned hwid = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));        // HW_REG_HW_ID
-        const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));        // HW_REG_XCC_ID
-        if (lane == 0) {
-            unsigned long long *o = reinterpret_cast<unsigned long long *>(p_.dbg) + (size_t)blockIdx.x * 8;
-            o[0] = tl0; o[1] = tl1; o[2] = tl2; o[3] = tl3; o[4] = tl4; o[5] = ((unsigned long long)xcc << 32) | hwid;
-            o[6] = ((tla - tl0) << 32) | ((tlb - tla) & 0xffffffffull); o[7] = tlc - tlb;
-        }
-    }
-#endif
+#undef W4_DBG_WRITE
 }
 
 }  // namespace
@@ -976,7 +1090,13 @@ hipError_t launch_wino4_conv(ConvKind kind, const ConvArgs &a, hipStream_t st)
             c &= ~7;                                       // whole slots on each of the 8 XCDs
             cus.store(c, std::memory_order_relaxed);
         }
-        if (nwg > c) grid = c;                            // one workgroup per CU walks the ids; small launches stay one tile per workgroup
+        long want = c;
+#ifdef ADN_EXPERIMENTS
+        // timing experiment: ADN_W4_GRID_MULT workgroups per CU queue up (each walks 1/MULT of the ids a resident one would)
+        static const int mult = []() { const char *e = std::getenv("ADN_W4_GRID_MULT"); return e ? std::atoi(e) : 1; }();
+        if (mult > 1) want = (long)c * mult;
+#endif
+        if (nwg > want) grid = want;                      // one workgroup per CU walks the ids; small launches stay one tile per workgroup
         else grid = (nwg + 7) & ~7L;
         if (grid < 8) grid = 8;
     }
@@ -1011,11 +1131,11 @@ hipError_t launch_wino4_conv(ConvKind kind, const ConvArgs &a, hipStream_t st)
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_conv_f32<CONV3X3_RELU, 128>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((wino4_conv_f32<CONV3X3_RELU, 128>), dim3((unsigned)nwg), dim3(NT), LDS_BYTES, st, a2);
+            hipLaunchKernelGGL((wino4_conv_f32<CONV3X3_RELU, 128>), dim3((unsigned)grid), dim3(NT), LDS_BYTES, st, a2);
         } else if (kind == CONV3X3_RELU_POOL)
-            hipLaunchKernelGGL(wino4_conv_f32<CONV3X3_RELU_POOL>, dim3((unsigned)nwg), dim3(NT), LDS_BYTES, st, a2);
+            hipLaunchKernelGGL(wino4_conv_f32<CONV3X3_RELU_POOL>, dim3((unsigned)grid), dim3(NT), LDS_BYTES, st, a2);
         else
-            hipLaunchKernelGGL(wino4_conv_f32<CONV3X3_RELU>, dim3((unsigned)nwg), dim3(NT), LDS_BYTES, st, a2);
+            hipLaunchKernelGGL(wino4_conv_f32<CONV3X3_RELU>, dim3((unsigned)grid), dim3(NT), LDS_BYTES, st, a2);
         (void)hipStreamSynchronize(st);
         std::vector<unsigned long long> hb(bytes / 8);
         (void)hipMemcpy(hb.data(), a2.dbg, bytes, hipMemcpyDeviceToHost);
@@ -1069,7 +1189,7 @@ hipError_t launch_wino4_conv(ConvKind kind, const ConvArgs &a, hipStream_t st)
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         if (e != hipSuccess) return e;
         void *args[] = {&a2};
-        return hipLaunchKernel(f, dim3((unsigned)nwg), dim3(NT), args, LDS_BYTES, st);
+        return hipLaunchKernel(f, dim3((unsigned)grid), dim3(NT), args, LDS_BYTES, st);
     }
     if (a2.ablate) {
         const void *f = nullptr;
@@ -1083,7 +1203,7 @@ hipError_t launch_wino4_conv(ConvKind kind, const ConvArgs &a, hipStream_t st)
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         if (e != hipSuccess) return e;
         void *args[] = {&a2};
-        return hipLaunchKernel(f, dim3((unsigned)nwg), dim3(NT), args, LDS_BYTES, st);
+        return hipLaunchKernel(f, dim3((unsigned)grid), dim3(NT), args, LDS_BYTES, st);
     }
 #endif
     static_assert(8 * (256 * 17 + 32) * sizeof(float) <= LDS_BYTES, "staging of the fused 1x1 epilogue must fit the images");
