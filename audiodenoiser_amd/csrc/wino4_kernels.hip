@@ -86,6 +86,14 @@ constexpr int KC = 8;                        // input channels per chunk
 #ifndef W4_FASTDIV                            // 1: tile decode by multiply-high with launch constants instead of seven software divisions
 #define W4_FASTDIV 1
 #endif
+#ifndef W4_NT_STORES                          // 1: the epilogue's output stores carry the non-temporal hint (timing experiment)
+#define W4_NT_STORES 0
+#endif
+#if W4_NT_STORES
+#define W4_ST(lv, val) __builtin_nontemporal_store((val), &(lv))
+#else
+#define W4_ST(lv, val) (lv) = (val)
+#endif
 #ifndef W4_EPI_PK                             // output transform on register pairs in packed fp32: 1 = pooling variant, 2 = plain variant too
 #define W4_EPI_PK 1
 #endif
@@ -941,10 +949,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     for (int e = 0; e < 2; ++e) {
                         const float v = y[a][b][e];
                         if constexpr (INT) {
-                            if (!(ABL & 4096) || v == 123.456f) orow[a][(8 * rp + 4 * e + b) * 8] = v;
+                            if (!(ABL & 4096) || v == 123.456f) W4_ST(orow[a][(8 * rp + 4 * e + b) * 8], v);
                         } else {
                             if (clip_ok && gy + a < p.H && gx + 4 * e + b < p.W && (!(ABL & 4096) || v == 123.456f))
-                                ob[((size_t)(gy + a) * p.W + gx + 4 * e + b) * 8] = v;
+                                W4_ST(ob[((size_t)(gy + a) * p.W + gx + 4 * e + b) * 8], v);
                         }
                     }
             }
@@ -959,10 +967,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                         for (int e = 0; e < 2; ++e) {
                             const float mx = mx2[e];
                             if constexpr (INT) {
-                                if (!(ABL & 4096) || mx == 123.456f) prow[a][(4 * rp + 2 * e + b) * 8] = mx;
+                                if (!(ABL & 4096) || mx == 123.456f) W4_ST(prow[a][(4 * rp + 2 * e + b) * 8], mx);
                             } else {
                                 const int py = (gy >> 1) + a, px = (gx >> 1) + 2 * e + b;
-                                if (clip_ok && py < Hp && px < Wp && (!(ABL & 4096) || mx == 123.456f)) pb[((size_t)py * Wp + px) * 8] = mx;
+                                if (clip_ok && py < Hp && px < Wp && (!(ABL & 4096) || mx == 123.456f)) W4_ST(pb[((size_t)py * Wp + px) * 8], mx);
                             }
                         }
                     }
@@ -981,10 +989,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 for (int b = 0; b < 4; ++b) {
                     y[a][b] = fmaxf(W4_BIAS_ACC ? y[a][b] + o[b] : y[a][b] + o[b] + bias_r, 0.f);
                     if constexpr (INT) {
-                        if (!(ABL & 4096) || y[a][b] == 123.456f) orow[a][(4 * r + b) * 8] = y[a][b];
+                        if (!(ABL & 4096) || y[a][b] == 123.456f) W4_ST(orow[a][(4 * r + b) * 8], y[a][b]);
                     } else {
                         if (clip_ok && gy + a < p.H && gx + b < p.W && (!(ABL & 4096) || y[a][b] == 123.456f))
-                            ob[((size_t)(gy + a) * p.W + gx + b) * 8] = y[a][b];
+                            W4_ST(ob[((size_t)(gy + a) * p.W + gx + b) * 8], y[a][b]);
                     }
                 }
             }
@@ -995,10 +1003,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     for (int b = 0; b < 2; ++b) {
                         const float mx = fmaxf(fmaxf(y[2 * a][2 * b], y[2 * a][2 * b + 1]), fmaxf(y[2 * a + 1][2 * b], y[2 * a + 1][2 * b + 1]));
                         if constexpr (INT) {
-                            if (!(ABL & 4096) || mx == 123.456f) prow[a][(2 * r + b) * 8] = mx;
+                            if (!(ABL & 4096) || mx == 123.456f) W4_ST(prow[a][(2 * r + b) * 8], mx);
                         } else {
                             const int py = (gy >> 1) + a, px = (gx >> 1) + b;
-                            if (clip_ok && py < Hp && px < Wp && (!(ABL & 4096) || mx == 123.456f)) pb[((size_t)py * Wp + px) * 8] = mx;
+                            if (clip_ok && py < Hp && px < Wp && (!(ABL & 4096) || mx == 123.456f)) W4_ST(pb[((size_t)py * Wp + px) * 8], mx);
                         }
                     }
             }
