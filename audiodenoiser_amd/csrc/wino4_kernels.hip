@@ -271,7 +271,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // workgroup timeline (ADN_W4_TIMELINE, p.dbg != nullptr): clock at entry / first chunk ready / loop done / stores issued /
     // stores drained + the hardware id of the CU, written by wave 0; launch_wino4_conv prints the per-CU averages
     unsigned long long tl0 = __builtin_amdgcn_s_memtime();
-    unsigned long long tl1 = 0, tl2 = 0, tla = 0, tlb = 0, tlc = 0;
+    unsigned long long tl1 = 0, tl2 = 0, tla = 0, tlb = 0, tlc = 0, tle1 = 0, tle2 = 0;
 #endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -803,7 +803,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         for (int a = 0; a < 4; ++a) *reinterpret_cast<f32x4 *>(xb + (r * 4 + a) * 256) = f32x4{y[a][0], y[a][1], y[a][2], y[a][3]};
     }
     }
+#ifdef ADN_EXPERIMENTS
+    tle1 = __builtin_amdgcn_s_memtime();                // exchange block written
+#endif
     __syncthreads();
+#ifdef ADN_EXPERIMENTS
+    tle2 = __builtin_amdgcn_s_memtime();                // every wave's exchange block written
+#endif
     const float *xr = smem + ((tb * 2 + (jh ^ 1)) * 16 * 64 + el) * 4;  // the partner's block: its sum for OUR cout block
     if constexpr (SWP) {
         // Register r of the partial sums is cout 4 eq + r of tile eti: the 4x4 pixels of the tile x 4 consecutive couts leave
@@ -1026,7 +1032,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         if (lane == 0) {                                                                                           \
             unsigned long long *o = reinterpret_cast<unsigned long long *>(p_.dbg) + (size_t)(rec) * 8;            \
             o[0] = tl0; o[1] = tl1; o[2] = tl2; o[3] = tl3; o[4] = tl4; o[5] = ((unsigned long long)xcc << 32) | hwid; \
-            o[6] = ((tla - tl0) << 32) | ((tlb - tla) & 0xffffffffull); o[7] = tlc - tlb;                          \
+            o[6] = ((tla - tl0) << 32) | ((tlb - tla) & 0xffffffffull);                                            \
+            o[7] = ((tlc - tlb) & 0xfffffull) | (((tle1 - tl2) & 0xfffffull) << 20) | (((tle2 - tl2) & 0xfffffull) << 40); \
         }                                                                                                          \
     }
 #else
@@ -1157,9 +1164,12 @@ hipError_t launch_wino4_conv(ConvKind kind, const ConvArgs &a, hipStream_t st)
                 recs.push_back({key, hb[b * 8], hb[b * 8 + 1], hb[b * 8 + 2], hb[b * 8 + 3], hb[b * 8 + 4]});
             }
         std::sort(recs.begin(), recs.end(), [](const Rec &x, const Rec &y) { return x.key != y.key ? x.key < y.key : x.t0 < y.t0; });
-        double pro = 0, loop = 0, epi = 0, drain = 0, gap = 0, span = 0, dec = 0, iss = 0, land = 0;
+        double pro = 0, loop = 0, epi = 0, drain = 0, gap = 0, span = 0, dec = 0, iss = 0, land = 0, ex1 = 0, ex2 = 0;
         for (long b = 0; b < nwg; ++b)
-            if (hb[b * 8 + 4]) { dec += (double)(hb[b * 8 + 6] >> 32); iss += (double)(hb[b * 8 + 6] & 0xffffffffull); land += (double)hb[b * 8 + 7]; }
+            if (hb[b * 8 + 4]) {
+                dec += (double)(hb[b * 8 + 6] >> 32); iss += (double)(hb[b * 8 + 6] & 0xffffffffull); land += (double)(hb[b * 8 + 7] & 0xfffffull);
+                ex1 += (double)((hb[b * 8 + 7] >> 20) & 0xfffffull); ex2 += (double)((hb[b * 8 + 7] >> 40) & 0xfffffull);
+            }
         long ngap = 0, ncu = 0;
         unsigned long long first = ~0ull, last = 0;
         for (size_t i = 0; i < recs.size(); ++i) {
@@ -1176,8 +1186,9 @@ hipError_t launch_wino4_conv(ConvKind kind, const ConvArgs &a, hipStream_t st)
         const double nr = recs.empty() ? 1.0 : (double)recs.size();
         std::fprintf(stderr, "[w4 timeline] H %d W %d nchunk %d Cout %d: %zu workgroups on %ld CUs, clocks per workgroup: prologue %.0f  "
                              "K loop %.0f (%.0f per chunk)  epilogue %.0f  store drain %.0f  gap to the next workgroup on the CU %.0f;  "
-                             "launch span %.0f clocks; prologue = decode %.0f + copies issued %.0f + landed %.0f + barrier\n", a2.H, a2.W, a2.nchunk, a2.Cout, recs.size(), ncu, pro / nr, loop / nr,
-                     loop / nr / a2.nchunk, epi / nr, drain / nr, ngap ? gap / ngap : 0.0, span, dec / nr, iss / nr, land / nr);
+                             "launch span %.0f clocks; prologue = decode %.0f + copies issued %.0f + landed %.0f + barrier; epilogue (wave 0) = exchange written %.0f, "
+                             "barrier passed %.0f, stores issued %.0f\n", a2.H, a2.W, a2.nchunk, a2.Cout, recs.size(), ncu, pro / nr, loop / nr,
+                     loop / nr / a2.nchunk, epi / nr, drain / nr, ngap ? gap / ngap : 0.0, span, dec / nr, iss / nr, land / nr, ex1 / nr, ex2 / nr, epi / nr);
         return hipGetLastError();
     }
 #endif
