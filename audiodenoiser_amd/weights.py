@@ -147,6 +147,68 @@ def make_state_dict(seed: int = 1234, in_channels: int = 1, num_classes: int = 1
     return sd
 
 
+WEIGHT_VARIANTS = ("benign", "trained", "heavy")
+
+
+def make_state_dict_variant(kind: str, seed: int = 1234, in_channels: int = 1,
+                            num_classes: int = 1) -> "OrderedDict[str, np.ndarray]":
+    """Parameter distributions a real checkpoint could have and ``make_state_dict`` (kind "benign") never shows the kernels.
+
+    * ``"trained"``: torch-default-scale convolutions (``kaiming_uniform_(a=sqrt(5))``: weights and biases uniform
+      (+-1/sqrt(fan_in)); ConvTranspose2d uses torch's fan_in = Cout*4) and "trained-like" BatchNorm — ``running_var``
+      log-uniform in [1e-3, 1e2], ``weight`` (gamma) uniform in [-1.5, 1.5] (negative and near-zero gammas included),
+      ``bias`` and ``running_mean`` uniform in [-1, 1].  The folded per-channel scale gamma/sqrt(var+eps) spans 0 .. 47.
+    * ``"heavy"``: the benign weights with heavy tails — in every convolution / transposed-convolution weight tensor
+      8 hash-chosen elements are multiplied by 20 (outliers the Winograd weight transform G g G^T spreads over a whole
+      6x6 block).
+    Same counter-based PRNG as ``make_state_dict``: bit-identical on every host.
+    """
+    if kind == "benign":
+        return make_state_dict(seed, in_channels, num_classes)
+    if kind not in WEIGHT_VARIANTS:
+        raise ValueError(f"unknown weight variant {kind!r}; expected one of {WEIGHT_VARIANTS}")
+    if kind == "heavy":
+        sd = make_state_dict(seed, in_channels, num_classes)
+        for key, v in sd.items():
+            if v.ndim == 4:
+                u = hash_uniform(seed, "outlier:" + key, 8).astype(np.float64)
+                idx = np.minimum((u * v.size).astype(np.int64), v.size - 1)
+                flat = v.reshape(-1)
+                flat[idx] = flat[idx] * np.float32(20.0)
+        return sd
+    sd: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    two = np.float32(2.0)
+    one = np.float32(1.0)
+    last_fan_in = 1
+    for key, shape in state_dict_schema(in_channels, num_classes).items():
+        n = int(np.prod(shape)) if shape else 1
+        if key.endswith("num_batches_tracked"):
+            sd[key] = np.array(100, dtype=np.int64)
+            continue
+        u = hash_uniform(seed, "trained:" + key, n)
+        leaf = key.rsplit(".", 1)[1]
+        is_bn = len(shape) == 1 and (".double_conv.1." in key or ".double_conv.4." in key)
+        if is_bn:
+            if leaf == "running_var":
+                # log-uniform-like over 2^-10 .. 2^6 * 1.64 (9.8e-4 .. 105) from IEEE-exact operations only (no libm pow, whose last
+                # bit may differ between hosts): var = 2^floor(e) * (1 + frac(e)), e = -10 + 16.64 u
+                e = np.float64(-10.0) + np.float64(16.64) * u.astype(np.float64)
+                k = np.floor(e)
+                v = np.ldexp(1.0 + (e - k), k.astype(np.int64)).astype(np.float32)
+            elif leaf == "weight":
+                v = (u * two - one) * np.float32(1.5)
+            else:  # bias, running_mean
+                v = u * two - one
+        elif len(shape) == 4:
+            # torch: fan_in = size(1) * receptive field (for ConvTranspose2d's (Cin, Cout, 2, 2) that is Cout * 4)
+            last_fan_in = shape[1] * shape[2] * shape[3]
+            v = (u * two - one) * np.float32(1.0 / np.sqrt(last_fan_in))
+        else:  # bias of the convolution just defined
+            v = (u * two - one) * np.float32(1.0 / np.sqrt(last_fan_in))
+        sd[key] = np.asarray(v, dtype=np.float32).reshape(shape)
+    return sd
+
+
 def make_input(seed: int, n: int, f: int, t: int, scale: float = 3.0) -> np.ndarray:
     """Synthetic non-negative magnitude-like input ``(n, 1, f, t)`` fp32 = uniform[0,1) * scale."""
     u = hash_uniform(seed, "input", n * f * t)

@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import load_real_audio_fixture
+from conftest import VARIANT_KINDS, VARIANT_SHAPES, load_real_audio_fixture, load_variant_golden, variant_input
 import torch
 
 import oracle
@@ -113,3 +113,40 @@ def test_config0_real_audio_oracle_chain_matches_reference_golden(golden_dir, we
     sd = unet_torch.to_torch_state(weights_np)
     y = unet_torch.unet_forward(sd, torch.from_numpy(x[None, None])).numpy()[0, 0]
     assert np.abs(y - g["y"]).max() <= 1e-6 * np.abs(g["y"]).max()
+
+
+# ---- goldens under parameter distributions the benign set never shows (tools/make_golden.py --only variants) ----
+@pytest.mark.parametrize("kind", VARIANT_KINDS)
+@pytest.mark.parametrize("f,t", VARIANT_SHAPES)
+def test_torch_oracle_matches_variant_goldens(golden_dir, variant_weights, kind, f, t):
+    """Trained-like BatchNorm statistics (running_var over five decades, negative gammas) and heavy-tailed weights, real-audio
+    magnitudes at scale 1 and 100: the reference's own forward (model.py:53-94) froze these; the torch restatement must
+    reproduce them like the benign ones."""
+    g = load_variant_golden(golden_dir, kind, f, t)
+    sd = unet_torch.to_torch_state(variant_weights(kind))
+    y, taps = unet_torch.unet_forward(sd, torch.from_numpy(variant_input(golden_dir, f, t)), want_taps=True)
+    ref = g["y"]
+    assert ref.shape == (2, 1, f, t) and np.isfinite(ref).all()
+    for clip in range(2):                                       # per clip: the x100 clip must not mask the other
+        assert np.abs(y.numpy()[clip] - ref[clip]).max() <= 1e-6 * np.abs(ref[clip]).max(), clip
+    _check_taps(g, {k: v.numpy() for k, v in taps.items()}, 1e-6)
+
+
+@pytest.mark.parametrize("kind", VARIANT_KINDS)
+def test_c_oracle_matches_variant_golden_small(golden_dir, variant_weights, kind):
+    g = load_variant_golden(golden_dir, kind, 33, 47)
+    y, taps = oracle.unet_forward(variant_weights(kind), variant_input(golden_dir, 33, 47), acc64=True, want_taps=True)
+    for clip in range(2):
+        assert np.abs(y[clip] - g["y"][clip]).max() <= 1e-5 * np.abs(g["y"][clip]).max(), clip
+    _check_taps(g, taps, 1e-5)
+
+
+def test_weight_variants_are_what_they_claim(variant_weights):
+    tr, hv = variant_weights("trained"), variant_weights("heavy")
+    var = np.concatenate([v.ravel() for k, v in tr.items() if k.endswith("running_var")])
+    gam = np.concatenate([v.ravel() for k, v in tr.items() if ".double_conv." in k and k.endswith((".1.weight", ".4.weight"))])
+    assert 9e-4 < var.min() < 2e-3 and 50 < var.max() <= 105          # five decades
+    assert gam.min() < -1.4 and gam.max() > 1.4 and np.abs(gam).min() < 1e-3
+    w = hv["bottleneck.double_conv.3.weight"].ravel()
+    bound = np.sqrt(6.0 / (1024 * 9))
+    assert (np.abs(w) > 5 * bound).sum() in range(1, 9)               # the 8 outliers (fewer if two hashes collide / tiny values)

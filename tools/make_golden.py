@@ -17,6 +17,9 @@ What is frozen:
   ``tools/make_real_audio_fixture.py`` -> STFT 1024/256 centred (CPU oracle; librosa is absent, that stage is parity
   unpinned) saved as .npy -> the reference's ``SpectrogramDataset(target_size=(513, 256))`` -> the reference's
   ``UNet.forward``.  Stored: ``x_f16`` (the loader's output, exactly representable in fp16) and ``y``.
+* ``unet_{trained,heavy}_<F>x<T>.npz`` (``--only variants``) — the reference forward under two more seeded parameter sets
+  (``audiodenoiser_amd.weights.make_state_dict_variant``: trained-like BatchNorm statistics / heavy-tailed weights) on the
+  real-audio input above cropped to (F, T), two clips at scale 1 and 100.
 """
 from __future__ import annotations
 
@@ -33,7 +36,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, "/root/reference/code")
 
-from audiodenoiser_amd.weights import hash_uniform, make_input, make_state_dict  # noqa: E402
+from audiodenoiser_amd.weights import hash_uniform, make_input, make_state_dict, make_state_dict_variant  # noqa: E402
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 WEIGHT_SEED = 1234
@@ -77,9 +80,65 @@ def config0_real_audio() -> None:
           f"std {float(y.std()):.4f}")
 
 
+VARIANT_KINDS = ("trained", "heavy")
+VARIANT_SHAPES = ((33, 47), (257, 188), (513, 256))
+REF_MODULES = ("downconv1", "downconv2", "downconv3", "downconv4", "bottleneck", "upconv1", "upconv2", "upconv3", "upconv4", "out")
+
+
+def variant_input(golden_dir: str, f: int, t: int) -> np.ndarray:
+    """Input of the weight-variant goldens: the real-audio network input of configs[0] (``config0_real_audio.npz``: the
+    reference loader's fp16-rounded 513x256 magnitude) cropped to (f, t) by the loader rule (top-left), as two clips:
+    clip 0 at scale 1, clip 1 at scale 100 (fp32 product)."""
+    x16 = np.load(os.path.join(golden_dir, "config0_real_audio.npz"))["x_f16"]
+    x = x16[:f, :t].astype(np.float32)
+    return np.stack([x, x * np.float32(100.0)])[:, None]
+
+
+def weight_variants() -> None:
+    """``unet_<kind>_<F>x<T>.npz``: the reference's ``UNet.forward`` (code/model.py:53-94) under parameter distributions the
+    benign goldens never show (``make_state_dict_variant``: trained-like BatchNorm statistics, heavy-tailed weights) on
+    real-audio magnitudes at scale 1 and 100.  Same record layout as ``unet_<F>x<T>.npz``."""
+    import model as ref_model  # reference code/model.py
+
+    torch.set_num_threads(os.cpu_count() or 1)
+    for kind in VARIANT_KINDS:
+        net = ref_model.UNet(in_channels=1, num_classes=1)
+        sd = make_state_dict_variant(kind, WEIGHT_SEED)
+        net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, strict=True)
+        net.eval()
+        acts = {}
+
+        def hook(name):
+            def fn(_mod, _inp, out):
+                acts[name] = (out[0] if isinstance(out, tuple) else out).detach()
+            return fn
+
+        for mod_name in REF_MODULES:
+            getattr(net, mod_name).register_forward_hook(hook(mod_name))
+        for f, t in VARIANT_SHAPES:
+            x = torch.from_numpy(variant_input(GOLDEN, f, t))
+            with torch.no_grad():
+                y = net(x)
+            assert bool(torch.isfinite(y).all()), (kind, f, t)
+            rec = {"y": y.numpy().astype(np.float32), "shape": np.array([2, f, t]), "weight_seed": np.array(WEIGHT_SEED)}
+            line = []
+            for mod_name, key in zip(REF_MODULES, TAP_KEYS):
+                a = acts[mod_name].numpy().astype(np.float64).ravel()
+                idx = sample_indices(key, a.size)
+                rec[f"{key}_stats"] = np.array([a.sum(), np.abs(a).sum(), (a * a).sum(), a.size], dtype=np.float64)
+                rec[f"{key}_idx"] = idx
+                rec[f"{key}_val"] = a[idx].astype(np.float32)
+                line.append(f"{key} {np.abs(a).max():.3g}")
+            path = os.path.join(GOLDEN, f"unet_{kind}_{f}x{t}.npz")
+            np.savez_compressed(path, **rec)
+            print(f"wrote {path} ({os.path.getsize(path)} B): y mean {float(y.mean()):+.4g} std {float(y.std()):.4g}; max|tap|: " + ", ".join(line))
+
+
 def main() -> None:
     if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "config0":
         return config0_real_audio()
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "variants":
+        return weight_variants()
     import data_loader as ref_loader  # reference code/data_loader.py
     import model as ref_model  # reference code/model.py
 
@@ -143,6 +202,7 @@ def main() -> None:
     np.savez_compressed(path, **rec)
     print("wrote", path)
     config0_real_audio()
+    weight_variants()
 
 
 if __name__ == "__main__":
