@@ -30,6 +30,19 @@ int fail_hip(hipError_t e, const char *what)
         hipError_t e_ = (call);                         \
         if (e_ != hipSuccess) return fail_hip(e_, #call); \
     } while (0)
+// launches that may need a constant table: a cold lookup on a capturing stream is the CALLER's error (adn.h, Conventions)
+int fail_launch(hipError_t e, const char *what)
+{
+    if (e == adn::ADN_COLD_IN_CAPTURE)
+        return fail(ADN_ERR_INVALID, std::string(what) + ": first use of this (device, n_fft) on a stream that is being captured -- the "
+                    "constant tables are built with a blocking upload; call adn_prepare(device, n_fft) before the capture");
+    return fail_hip(e, what);
+}
+#define ADN_LAUNCH(call, what)                          \
+    do {                                                \
+        hipError_t e_ = (call);                         \
+        if (e_ != hipSuccess) return fail_launch(e_, what); \
+    } while (0)
 
 // Switches the calling thread to `device` for the lifetime of the guard and restores the caller's device on every
 // exit path: no entry point leaves a hidden side effect on the caller's HIP state (adn.h, Conventions).
@@ -96,6 +109,13 @@ struct adn_unet {
     // accumulation; conv_dma<..., SPLIT>): fp32-level accuracy at 3/8 of the exact-fp32 matrix time.  ADN_CONVT_SPLIT=0 when the
     // handle is created keeps the exact-fp32 MFMA form.
     bool convt_split = true;
+    // Small grids (one or a few clips): a 3x3 layer whose F(4x4,3x3) launch would be fewer than `auto_grid` workgroups (2 per CU)
+    // runs on the finer-grained F(2x2,3x3) kernel instead, cut along K where even that grid cannot fill the chip
+    // (choose_algo below).  The choice then depends on the batch size, so the same clip computed alone or inside a large batch
+    // differs in the last bits (both within 1e-4 of the reference).  ADN_BATCH_INVARIANT=1 when the handle is created pins one
+    // kernel per layer by geometry alone: a clip's result is bit-identical whatever batch it is computed in.
+    bool batch_invariant = false;
+    long auto_grid = 512;
     size_t zeros_off = 0;          // 64 zero floats inside the packed buffer
 };
 
@@ -263,7 +283,10 @@ void pack_convt_split(const float *w /*(Cin,Cout,2,2)*/, int Cin, int Cout, uint
                         for (int kk = 0; kk < 8; ++kk) {
                             const int ci = ch * KC + 8 * h + kk;
                             const float v = w[((size_t)ci * Cout + co) * 4 + ij];
-                            const uint16_t hi = bf16_rne(v);
+                            uint16_t hi = bf16_rne(v);
+                            // a finite weight in the top 0.2 % of fp32's range rounds to a bf16 infinity: largest finite bf16 instead
+                            // (split3_bf16 in conv_kernels.hip clamps the activations the same way); the residuals stay finite
+                            if ((hi & 0x7fffu) == 0x7f80u && std::isfinite(v)) hi = (uint16_t)((hi & 0x8000u) | 0x7f7fu);
                             const float r1 = v - bf16_to_float(hi);
                             const uint16_t mid = bf16_rne(r1);
                             const float r2 = r1 - bf16_to_float(mid);
@@ -369,13 +392,48 @@ adn::ConvArgs conv_args(const adn_unet *h, const Conv3x3Layer &L, adn::ConvKind 
     return a;
 }
 
+// Which kernel runs a 3x3 layer of the fp32 Winograd path, and how many K splits.
+struct Algo {
+    bool f4;       // F(4x4,3x3) (wino4_conv_f32) instead of F(2x2,3x3)
+    int ksplit;    // > 1: split-K on F(2x2,3x3) + reduce launch
+};
+
+// workgroups of the F(4x4,3x3) launch of a layer (launch_wino4_conv's grid without the supertile padding)
+long wino4_grid(const adn::ConvArgs &a)
+{
+    const int pair = a.W <= 16 ? 1 : 0;
+    return (long)((a.N + pair) >> pair) * ((a.H + 31) / 32) * ((a.W + 31) / 32) * (a.Cout / 32);
+}
+
+Algo choose_algo(const adn_unet *h, adn::ConvKind kind, const adn::ConvArgs &a)
+{
+    Algo r{false, 1};
+    const bool can_split = kind != adn::CONV3X3_RELU_DOT && !a.firstw;
+    adn::ConvArgs probe = a;
+    probe.ksplit = 1;
+    const bool f4_ok = a.wpk4 && adn::wino4_applicable(kind, probe, h->force_wino4);
+    if (h->allow_split && can_split) {                   // ADN_WINO_SPLITK=1: split wherever the F(2x2,3x3) grid cannot fill the chip
+        r.ksplit = adn::wino_ksplit(adn::wino_workgroups(a), a.nchunk);
+        r.f4 = r.ksplit == 1 && f4_ok;
+        return r;
+    }
+    if (!f4_ok) return r;
+    if (h->batch_invariant || h->force_wino4 || wino4_grid(a) >= h->auto_grid) {
+        r.f4 = true;
+        return r;
+    }
+    if (can_split) r.ksplit = adn::wino_ksplit(adn::wino_workgroups(a), a.nchunk);      // small grid: F(2x2,3x3), cut along K if needed
+    return r;
+}
+
 hipError_t launch_conv3(const adn_unet *h, adn::ConvKind kind, const adn::ConvArgs &a, float *partial, hipStream_t st)
 {
     if (!h->use_wino) return adn::launch_conv_mfma(kind, a, h->f16, st);
     adn::ConvArgs a2 = a;
-    a2.ksplit = (h->allow_split && kind != adn::CONV3X3_RELU_DOT) ? adn::wino_ksplit(adn::wino_workgroups(a), a.nchunk) : 1;
+    const Algo algo = choose_algo(h, kind, a);
+    a2.ksplit = algo.ksplit;
     a2.partial = partial;
-    if (a2.wpk4 && adn::wino4_applicable(kind, a2, h->force_wino4)) {
+    if (algo.f4) {
         a2.wpk = a2.wpk4;
         return adn::launch_wino4_conv(kind, a2, st);
     }
@@ -420,16 +478,11 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
     // tile by tile inside that kernel and never written (timing slot 0 stays empty).
     bool fused_first = h->use_wino;
     if (fused_first) {
-        adn::ConvArgs probe{};
-        probe.N = N; probe.H = p.H[0]; probe.W = p.W[0];
-        probe.Cout = 64; probe.nchunk = 64 / 8; probe.ksplit = 1;
         // where the F(4x4,3x3) kernel takes down1's second conv the first layer runs as its own launch (the fused form is
-        // time-neutral on F(2x2,3x3); unfused + F(4x4,3x3) is 1.1 ms faster at batch 64)
-        if (h->use_wino4 && adn::wino4_applicable(adn::CONV3X3_RELU_POOL, probe, h->force_wino4)) fused_first = false;
-        // split-K (opt-in, small batches) may cut down1's second conv along K: the fused form has no split variant
-        probe.tilesY = (p.H[0] + 15) / 16;
-        probe.nct = 64 / h->wino_bn;
-        if (h->allow_split && adn::wino_ksplit(adn::wino_workgroups(probe), 64 / 8) > 1) fused_first = false;
+        // time-neutral on F(2x2,3x3); unfused + F(4x4,3x3) is 1.1 ms faster at batch 64); split-K has no fused variant either
+        adn::ConvArgs probe = conv_args(h, h->c3[0], adn::CONV3X3_RELU_POOL, tA, 64, nullptr, 0, 0, 0, tA, tA, N, p.H[0], p.W[0]);
+        const Algo algo = choose_algo(h, adn::CONV3X3_RELU_POOL, probe);
+        if (algo.f4 || algo.ksplit > 1) fused_first = false;
     }
     ADN_MARK();
     if (!fused_first)
@@ -585,6 +638,23 @@ int adn_device_count(int *count)
     return ADN_OK;
 }
 
+int adn_prepare(int device, int n_fft)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(ADN_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= ndev) return fail(ADN_ERR_INVALID, "adn_prepare: bad device index");
+    if (n_fft != 0 && (n_fft < 64 || n_fft > 4096 || (n_fft & (n_fft - 1))))
+        return fail(ADN_ERR_INVALID, "adn_prepare: n_fft must be 0 (loss tables only) or a power of two in [64, 4096]");
+    DeviceGuard guard(device);
+    if (guard.err != hipSuccess) return fail_hip(guard.err, "hipSetDevice");
+    if (n_fft) {
+        const float *tables = nullptr;
+        ADN_LAUNCH(adn::stft_tables(n_fft, &tables, nullptr), "adn_prepare");
+    }
+    ADN_LAUNCH(adn::loss_tables(nullptr), "adn_prepare");
+    return ADN_OK;
+}
+
 int adn_unet_create(adn_unet **handle, int device, const float *const *t, int n_tensors)
 {
     return adn_unet_create_ex(handle, device, t, n_tensors, ADN_DTYPE_F32);
@@ -615,6 +685,8 @@ int adn_unet_create_ex(adn_unet **handle, int device, const float *const *t, int
     if (h->f16) h->use_wino = false;                           // the fp16 path runs the direct fp16-MFMA kernels
     if (const char *sk = std::getenv("ADN_WINO_SPLITK")) h->allow_split = std::atoi(sk) != 0;
     if (const char *cs = std::getenv("ADN_CONVT_SPLIT")) h->convt_split = std::atoi(cs) != 0;
+    if (const char *bi = std::getenv("ADN_BATCH_INVARIANT")) h->batch_invariant = std::atoi(bi) != 0;
+    if (const char *ag = std::getenv("ADN_AUTO_GRID")) h->auto_grid = std::atol(ag);      // tuning knob of the small-grid rule (0: never)
     if (h->f16) h->convt_split = false;
     if (const char *wt = std::getenv("ADN_WINO_TILE")) {
         h->use_wino4 = std::atoi(wt) != 2;
@@ -804,7 +876,7 @@ int adn_stft_mag(const float *audio, int n_clips, long length, int n_fft, int ho
     hipError_t e = adn::launch_stft_mag(audio, n_clips, length, n_fft, hop, center, nfr, out, nb, nfr, (long)nb * nfr, 0,
                                         static_cast<hipStream_t>(stream));
     if (e == hipErrorInvalidValue) return fail(ADN_ERR_INVALID, "adn_stft_mag: hop too large for on-chip staging or grid too large");
-    if (e != hipSuccess) return fail_hip(e, "stft launch");
+    if (e != hipSuccess) return fail_launch(e, "adn_stft_mag");
     return ADN_OK;
 }
 
@@ -822,12 +894,16 @@ int adn_stft_mag_fit(const float *audio, int n_clips, long length, int n_fft, in
     if (nfr <= 0) return fail(ADN_ERR_INVALID, "adn_stft_mag_fit: audio shorter than n_fft");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int nb = n_fft / 2 + 1;
+    {   // nothing is enqueued when the launch below is going to be refused (cold tables on a capturing stream)
+        const float *tables = nullptr;
+        ADN_LAUNCH(adn::stft_tables(n_fft, &tables, st), "adn_stft_mag_fit");
+    }
     // zero padding at the bottom / right of the window (data_loader.py:59-70) where the spectrogram is smaller than it
     if (W > nfr || H > nb) ADN_HIP(hipMemsetAsync(out, 0, (size_t)n_clips * H * W * sizeof(float), st));
     const long nfc = nfr < W ? nfr : W;                   // frames that fall inside the window: the only ones computed
     hipError_t e = adn::launch_stft_mag(audio, n_clips, length, n_fft, hop, center, nfc, out, nb < H ? nb : H, W, (long)H * W, 1, st);
     if (e == hipErrorInvalidValue) return fail(ADN_ERR_INVALID, "adn_stft_mag_fit: hop too large for on-chip staging or grid too large");
-    if (e != hipSuccess) return fail_hip(e, "stft launch");
+    if (e != hipSuccess) return fail_launch(e, "adn_stft_mag_fit");
     return ADN_OK;
 }
 
@@ -866,8 +942,8 @@ int adn_perceptual_loss(const float *pred, const float *target, int n_clips, int
                                      "the 160 KiB LDS of a CU)");
     const size_t need = adn::perceptual_loss_workspace_floats(n_clips, F, T) * sizeof(float);
     if (!workspace || workspace_bytes < need) return fail(ADN_ERR_WORKSPACE, "adn_perceptual_loss: workspace too small");
-    ADN_HIP(adn::launch_perceptual_loss(pred, target, n_clips, F, T, static_cast<float *>(workspace), out,
-                                        static_cast<hipStream_t>(stream)));
+    ADN_LAUNCH(adn::launch_perceptual_loss(pred, target, n_clips, F, T, static_cast<float *>(workspace), out,
+                                           static_cast<hipStream_t>(stream)), "adn_perceptual_loss");
     return ADN_OK;
 }
 
@@ -889,7 +965,8 @@ int adn_stft_complex(const float *audio, int n_clips, long length, int n_fft, in
     const long T = 1 + length / hop;
     if (T > 0x7fffffffL) return fail(ADN_ERR_INVALID, "adn_stft_complex: too many frames");
     if (!aligned_to(spec_out, 8)) return fail(ADN_ERR_INVALID, "adn_stft_complex: spec_out must be 8-byte aligned");
-    ADN_HIP(adn::launch_stft_complex(audio, n_clips, length, n_fft, hop, (int)T, spec_out, static_cast<hipStream_t>(stream)));
+    ADN_LAUNCH(adn::launch_stft_complex(audio, n_clips, length, n_fft, hop, (int)T, spec_out, static_cast<hipStream_t>(stream)),
+               "adn_stft_complex");
     return ADN_OK;
 }
 
@@ -910,7 +987,7 @@ int adn_istft(const float *spec, int n_clips, int n_frames, int n_fft, int hop, 
     if (!workspace || workspace_bytes < need) return fail(ADN_ERR_WORKSPACE, "adn_istft: workspace too small");
     if (!aligned_to(spec, 8) || !aligned_to(workspace, 8)) return fail(ADN_ERR_INVALID, "adn_istft: spec and workspace must be 8-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    ADN_HIP(adn::launch_istft_frames(spec, n_clips, n_frames, n_fft, static_cast<float *>(workspace), st));
+    ADN_LAUNCH(adn::launch_istft_frames(spec, n_clips, n_frames, n_fft, static_cast<float *>(workspace), st), "adn_istft");
     ADN_HIP(adn::launch_istft_ola(static_cast<const float *>(workspace), n_clips, n_frames, n_fft, hop, audio_out, st));
     return ADN_OK;
 }
@@ -939,6 +1016,10 @@ int adn_griffin_lim(const float *magnitude, const float *rnd, int n_clips, int n
     float *spec = static_cast<float *>(workspace);
     float *buf = spec + (size_t)n_clips * n_frames * n_bins * 2;
     const long len = (long)hop * (n_frames - 1);
+    {
+        const float *tables = nullptr;
+        ADN_LAUNCH(adn::stft_tables(n_fft, &tables, st), "adn_griffin_lim");
+    }
     ADN_HIP(adn::launch_gl_polar(magnitude, rnd, n_clips, n_bins, n_frames, spec, st));
     for (int it = 0; it <= iterations; ++it) {
         ADN_HIP(adn::launch_istft_frames(spec, n_clips, n_frames, n_fft, buf, st));

@@ -144,7 +144,13 @@ hipError_t launch_nhwc_to_nchw(const void *in, bool f16, float *out, int N, int 
 
 hipError_t launch_stft_mag(const float *audio, int n_clips, long L, int n_fft, int hop, int center, long n_frames,
                            float *out, int rows, long row_stride, long clip_stride, int quantize, hipStream_t st);
-hipError_t stft_tables(int n_fft, const float **out);
+// Constant tables are built on first use per (device, n_fft) / per device: a blocking hipMalloc + hipMemcpy.  On a stream
+// that is being captured nothing may block or allocate: a cold lookup there returns ADN_COLD_IN_CAPTURE (the ABI turns it into
+// ADN_ERR_INVALID with a message that names adn_prepare); adn_prepare builds the tables ahead of time.
+constexpr hipError_t ADN_COLD_IN_CAPTURE = hipErrorStreamCaptureUnsupported;
+bool stream_is_capturing(hipStream_t st);
+hipError_t stft_tables(int n_fft, const float **out, hipStream_t st);
+hipError_t loss_tables(hipStream_t st);      // mel filterbank of adn_perceptual_loss on the current device
 // Griffin-Lim building blocks (gl_kernels.hip); complex spectrograms are frame-major [clip][frame][F] float2
 hipError_t launch_gl_polar(const float *mag, const float *rnd, int n_clips, int F, int T, void *spec, hipStream_t st);
 hipError_t launch_istft_frames(const void *spec, int n_clips, int T, int n_fft, float *buf, hipStream_t st);

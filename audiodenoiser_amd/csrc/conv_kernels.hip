@@ -498,23 +498,28 @@ struct DmaCfg {
 
 // SPLIT = 1 (fp32 storage only; the transposed convolutions): the contraction runs on the BF16 matrix cores (16x the exact-fp32
 // MFMA rate) without giving up fp32 accuracy.  Every fp32 operand is split into three bf16 terms, x = hi + mid + lo (24 mantissa
-// bits; bf16 has fp32's exponent range, so nothing needs scaling and nothing can overflow), and the six products of total order
+// bits; bf16 has fp32's exponent range, so nothing needs scaling), and the six products of total order
 // <= 2 -- hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid -- are accumulated in fp32 (the dropped terms are <= 2^-24 relative): the
 // result differs from an exact-fp32 MFMA sum by rounding noise (measured through the network: tools/report_parity.py).  Weights
 // are split on the host (pack_convt_split, adn_api.hip: three planes per 16-channel chunk), activations in registers after the LDS
 // read (v_cvt_pk_bf16_f32 + a subtraction per term).  6 x v_mfma_f32_32x32x16_bf16 (192 cycles) replace 8 x v_mfma_f32_32x32x2_f32
 // (512 cycles) per 32x32 tile and 16 channels.
+// Range: round-to-nearest turns |x| >= 3.3961e38 (the top 0.2 % of fp32's range) into a bf16 infinity, whose residual would be
+// -inf / NaN although x is finite; hi is therefore clamped to the largest finite bf16 (3.3895e38, one v_med3_f32): every FINITE
+// operand splits exactly.  Non-finite operands stay non-finite but not bit-compatible: x = +-inf gives hi = 3.39e38, mid = +-inf,
+// lo = NaN, so the sum is NaN where the exact-fp32 form may give +-inf (tests: test_convt_split_extreme_operands).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr float BF16_MAX_F = 0x1.fep127f;                  // largest finite bf16
 __device__ __forceinline__ void split3_bf16(const f32x4 &x0, const f32x4 &x1, bf16x8 &hi, bf16x8 &mid, bf16x8 &lo)
 {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const float x = e < 4 ? x0[e] : x1[e - 4];
-        const __bf16 h = (__bf16)x;
-        const float r1 = x - (float)h;
+        const float hf = __builtin_amdgcn_fmed3f((float)(__bf16)x, -BF16_MAX_F, BF16_MAX_F);
+        const float r1 = x - hf;
         const __bf16 m = (__bf16)r1;
         const float r2 = r1 - (float)m;
-        hi[e] = h;
+        hi[e] = (__bf16)hf;
         mid[e] = m;
         lo[e] = (__bf16)r2;
     }
@@ -932,7 +937,10 @@ hipError_t launch_conv_mfma_t(ConvKind kind, const ConvArgs &a, hipStream_t st)
         if (kind == CONV3X3_RELU_DOT) return hipErrorInvalidValue;     // fp32: only the Winograd kernel fuses the last layer
         if (kind == CONVT2X2) {
 #ifdef ADN_EXPERIMENTS
-            if (staging_regs()) return launch_cfg<T, 8, 128, 2, 2, 1, CONVT_KG, CONVT2X2>(a, st);
+            if (staging_regs()) {
+                if (a.split) return hipErrorInvalidValue;      // the register-staged kernel reads fp32-packed weights: create the handle with ADN_CONVT_SPLIT=0
+                return launch_cfg<T, 8, 128, 2, 2, 1, CONVT_KG, CONVT2X2>(a, st);
+            }
 #endif
             // a.split: weights packed as three bf16 planes (pack_convt_split): the split-bf16 form on the bf16 matrix cores
             if (a.split) return launch_dma_cfg<T, 8, 128, 2, 2, 1, CONVT_KG, CONVT2X2, 3, 1>(a, st);

@@ -241,7 +241,7 @@ hipError_t launch_gl_polar(const float *mag, const float *rnd, int n_clips, int 
 hipError_t launch_istft_frames(const void *spec, int n_clips, int T, int n_fft, float *buf, hipStream_t st)
 {
     const float *tables = nullptr;
-    hipError_t e = stft_tables(n_fft, &tables);
+    hipError_t e = stft_tables(n_fft, &tables, st);
     if (e != hipSuccess) return e;
     const float2 *s = static_cast<const float2 *>(spec);
     switch (n_fft) {
@@ -259,7 +259,7 @@ hipError_t launch_istft_frames(const void *spec, int n_clips, int T, int n_fft, 
 hipError_t launch_istft_ola(const float *buf, int n_clips, int T, int n_fft, int hop, float *audio, hipStream_t st)
 {
     const float *tables = nullptr;
-    hipError_t e = stft_tables(n_fft, &tables);
+    hipError_t e = stft_tables(n_fft, &tables, st);
     if (e != hipSuccess) return e;
     const long out_len = (long)hop * (T - 1);
     if (out_len <= 0) return hipErrorInvalidValue;
@@ -272,7 +272,7 @@ hipError_t launch_stft_complex(const float *audio, int n_clips, long L, int n_ff
                                hipStream_t st)
 {
     const float *tables = nullptr;
-    hipError_t e = stft_tables(n_fft, &tables);
+    hipError_t e = stft_tables(n_fft, &tables, st);
     if (e != hipSuccess) return e;
     float2 *s = static_cast<float2 *>(spec);
     const int pad = n_fft / 2;

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(const float *__restric
 std::mutex g_fb_mu;
 std::map<int, float *> g_fb;      // device -> mel filterbank
 
-hipError_t get_melfb(const float **out)
+hipError_t get_melfb(const float **out, hipStream_t st)
 {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -185,6 +185,7 @@ hipError_t get_melfb(const float **out)
     std::lock_guard<std::mutex> lk(g_fb_mu);
     auto it = g_fb.find(dev);
     if (it != g_fb.end()) { *out = it->second; return hipSuccess; }
+    if (stream_is_capturing(st)) return ADN_COLD_IN_CAPTURE;      // the upload below blocks: not inside a capture (adn_prepare)
     // torchaudio.functional.melscale_fbanks(n_freqs=32, f_min=0, f_max=4000, n_mels=64, sample_rate=8000,
     // norm=None, mel_scale="htk")
     const int nf = 32, nm = 64;
@@ -216,6 +217,12 @@ hipError_t get_melfb(const float **out)
 
 }  // namespace
 
+hipError_t loss_tables(hipStream_t st)
+{
+    const float *fb = nullptr;
+    return get_melfb(&fb, st);
+}
+
 // dynamic LDS of loss_finish_kernel: two T-long series, two 64-entry trig tables, 2 x 32 bins x (1 + T/16) mel frames
 size_t perceptual_loss_lds_bytes(int T) { return (size_t)(2 * T + 128 + 2 * 32 * (1 + T / 16)) * sizeof(float); }
 
@@ -229,7 +236,7 @@ hipError_t launch_perceptual_loss(const float *pred, const float *tgt, int n_cli
                                   float *out, hipStream_t st)
 {
     const float *fb = nullptr;
-    hipError_t e = get_melfb(&fb);
+    hipError_t e = get_melfb(&fb, st);
     if (e != hipSuccess) return e;
     const int nslab = (F + LOSS_ROWS - 1) / LOSS_ROWS;
     // everything that can fail is checked BEFORE the first launch (nothing is enqueued on an error)

@@ -828,7 +828,7 @@ struct TableKey {
 std::mutex g_table_mu;
 std::map<TableKey, float *> g_tables;
 
-hipError_t get_tables(int n_fft, const float **out)
+hipError_t get_tables(int n_fft, const float **out, hipStream_t st)
 {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -836,6 +836,7 @@ hipError_t get_tables(int n_fft, const float **out)
     std::lock_guard<std::mutex> lk(g_table_mu);
     auto it = g_tables.find(TableKey{dev, n_fft});
     if (it != g_tables.end()) { *out = it->second; return hipSuccess; }
+    if (stream_is_capturing(st)) return ADN_COLD_IN_CAPTURE;      // the upload below blocks: not inside a capture (adn_prepare)
     const int N = n_fft, M = N / 2;
     std::vector<float> h((size_t)N + 2 * M + (M + 2), 0.f);
     const double pi = 3.14159265358979323846;
@@ -887,7 +888,13 @@ hipError_t launch_m(const float *audio, int n_clips, long L, int hop, int pad, l
 
 // window / twiddle tables of one n_fft on the current device (cached): win[N], tw[M] = exp(-2 pi i j / M),
 // tw2[M/2+1] = exp(-2 pi i k / N); shared with the inverse-STFT kernels
-hipError_t stft_tables(int n_fft, const float **out) { return get_tables(n_fft, out); }
+hipError_t stft_tables(int n_fft, const float **out, hipStream_t st) { return get_tables(n_fft, out, st); }
+
+bool stream_is_capturing(hipStream_t st)
+{
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+}
 
 // n_frames = frames to compute per clip (all of them, or only those inside the fitted window); rows / row_stride /
 // clip_stride / quantize: see StftOut
@@ -896,7 +903,7 @@ hipError_t launch_stft_mag(const float *audio, int n_clips, long L, int n_fft, i
 {
     const StftOut o{row_stride, clip_stride, rows, quantize};
     const float *tables = nullptr;
-    hipError_t e = get_tables(n_fft, &tables);
+    hipError_t e = get_tables(n_fft, &tables, st);
     if (e != hipSuccess) return e;
     const int pad = center ? n_fft / 2 : 0;
 #ifdef ADN_EXPERIMENTS

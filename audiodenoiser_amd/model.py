@@ -88,7 +88,11 @@ class UNet(nn.Module):
 
     # ------------------------------------------------------------------ arithmetic type
     def set_compute_dtype(self, dtype: str):
-        """"f32" (default): exact-fp32 matrix cores, parity 1e-4 with the reference.  "f16": fp16 storage + fp16 MFMA
+        """"f32" (default): fp32 arithmetic, parity 1e-4 with the reference -- the 3x3 layers on the exact-fp32 matrix cores
+        (Winograd), the four transposed convolutions on the bf16 matrix cores through a three-term split of both fp32 operands
+        (six products, fp32 accumulation: fp32-level accuracy for every finite value; ``ADN_CONVT_SPLIT=0`` when the handle is
+        created keeps them on the exact-fp32 MFMA; non-finite activations give non-finite results in both forms, NaN where the
+        exact form may give inf).  "f16": fp16 storage + fp16 MFMA
         with fp32 accumulation inside the library (BASELINE configs[4]); inputs/outputs stay float32 tensors and the
         result is within 1e-2 of the fp32 path."""
         if dtype not in ("f32", "f16"):

@@ -36,18 +36,21 @@ def _wino4_tiled_area(h: int, w: int) -> int:
     return _ceil_to(h, 32) * 16 if w <= 16 else _ceil_to(h, 32) * _ceil_to(w, 32)
 
 
-def _wino4_computed_area(h: int, w: int) -> int:
-    """Pixels per clip the F(4x4,3x3) kernel runs MFMAs for: a workgroup tile is 2x2 blocks of 16x16 pixels and a block that
-    lies wholly outside the image does no arithmetic (``active`` in csrc/wino4_kernels.hip), so the image is padded to
-    multiples of 16, not 32 -- 528 rows for H = 513, not 544."""
-    return _ceil_to(h, 16) * 16 if w <= 16 else _ceil_to(h, 16) * _ceil_to(w, 16)
+def _wino4_computed_area(h: int, w: int, epi: str = "pool") -> int:
+    """Pixels per clip the F(4x4,3x3) kernel runs MFMAs for.  A workgroup tile is 2x2 blocks of 16x16 pixels.  In the pooling
+    and fused-1x1 variants (``epi`` "pool" / "dot": the kernel's LEAN form) a block that lies wholly outside the image does no
+    arithmetic (``if (LEAN && !active)`` in csrc/wino4_kernels.hip), so the image is padded to multiples of 16 -- 528 rows for
+    H = 513; the plain variant ("plain") has no such branch and computes whole 32x32 tiles -- 544 rows."""
+    m = 32 if epi == "plain" else 16
+    return _ceil_to(h, m) * 16 if w <= 16 else _ceil_to(h, m) * _ceil_to(w, m)
 
 
 def executed_mfma_flops(launch: dict, algo: str, wino_mode: str = "auto") -> float:
     """Matrix-core FLOPs one launch EXECUTES per sample, padded tiles counted (what `roofline.frac` is made of).
 
     ``algo``: "winograd" (fp32 default: wino4_conv_f32 = F(4x4,3x3), 36 multiply-adds per 4x4 output tile and (cin, cout)
-    pair = 4.5 FLOP per computed output pixel -- the 16x16-pixel blocks of its 32x32 tiles that touch the image --, where
+    pair = 4.5 FLOP per computed output pixel -- ``_wino4_computed_area``: by epilogue variant the 16x16-pixel blocks that
+    touch the image or whole 32x32 tiles --, where
     ``winograd_tile`` says so; wino_conv_dma_f32 =
     F(2x2,3x3), 16 multiply-adds per 2x2 tile = 8 FLOP per padded pixel on 16x16 tiles, elsewhere), "direct"
     (conv_mfma<float>: TH x 16 tiles with TH = 16 for the 64-channel layers and 8 otherwise, 18 FLOP per pixel) or
@@ -62,7 +65,7 @@ def executed_mfma_flops(launch: dict, algo: str, wino_mode: str = "auto") -> flo
         return 2.0 * cin * 4 * cout * _ceil_to(h, 8) * _ceil_to(w, 16)
     if algo == "winograd":
         if winograd_tile(launch, wino_mode) == 4:
-            return 4.5 * cin * cout * _wino4_computed_area(h, w)
+            return 4.5 * cin * cout * _wino4_computed_area(h, w, launch.get("epi", "plain"))
         return 8.0 * cin * cout * _ceil_to(h, 16) * _ceil_to(w, 16)
     th = 32 if algo == "direct_f16" else (16 if cout == 64 else 8)
     return 18.0 * cin * cout * _ceil_to(h, th) * _ceil_to(w, 16)
@@ -87,7 +90,9 @@ def unet_launches(f: int, t: int):
         if pool:
             act += 4.0 * cout * (h // 2) * (w // 2)
         wb = 4.0 * (cin * cout * k * k + cout)
-        out.append(dict(name=name, kind=kind, flops=flops, act_bytes=act, weight_bytes=wb, cin=cin, cout=cout, h=h, w=w))
+        # epilogue variant of the 3x3 kernels: pooling, plain, or (the network's last 3x3 layer) fused with the 1x1 output conv
+        epi = "pool" if pool else "dot" if name == "up4.conv2" else "plain"
+        out.append(dict(name=name, kind=kind, flops=flops, act_bytes=act, weight_bytes=wb, cin=cin, cout=cout, h=h, w=w, epi=epi))
 
     conv("down1.conv1", "first", 1, 64, hs[0], ws[0], 3)
     conv("down1.conv2+pool", "conv3x3", 64, 64, hs[0], ws[0], 3, pool=True)

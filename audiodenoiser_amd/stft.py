@@ -19,6 +19,14 @@ N_FFT = 512
 HOP_LENGTH = 128
 
 
+def prepare(device=None, n_fft: int = N_FFT) -> None:
+    """Build the constant tables of ``n_fft`` (and of the per-clip loss) on ``device`` ahead of time (``adn_prepare``): afterwards
+    the STFT-family calls and the loss only enqueue on the current stream, so they can be recorded into a HIP graph."""
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    _lib.check(_lib.load().adn_prepare(dev.index if dev.index is not None else torch.cuda.current_device(), int(n_fft)),
+               "adn_prepare")
+
+
 def stft_n_frames(length: int, n_fft: int, hop: int, center: bool) -> int:
     out = ctypes.c_long()
     _lib.check(_lib.load().adn_stft_n_frames(length, n_fft, hop, 1 if center else 0, ctypes.byref(out)),

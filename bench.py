@@ -35,7 +35,10 @@ Sub-benchmarks in the same JSON line (rank 0, N = 1 only; --no-extras skips them
   `fp32_b256`  the main step at batch 256 (north_star's batch, one rank's shard of configs[3]).
   `exact_f32`  the headline step with exact-fp32 matrix instructions everywhere (ADN_CONVT_SPLIT=0).
   `b1`    single-clip latency at 513x256 and the reference's own shapes (257x188 whole test set of 5 clips as test.py:112-113
-          runs it, 256x64 at the training batch of 16), default kernels and the single-clip serving switches.
+          runs it, 256x64 at the training batch of 16): default (automatic small-grid kernels), ADN_BATCH_INVARIANT=1, and the
+          explicit serving switches.
+  `e2e_config0`  BASELINE configs[0] as one stream sequence: resident audio -> adn_stft_mag_fit -> adn_unet_forward at batch 1
+          and 64, with the oracle chain's CPU time beside it.
   `stft`  BASELINE configs[2]: 10 000 clips x 132 300 samples, n_fft 1024, hop 256, centred; HBM roofline of
           stft_wave_kernel (algorithmic bytes = audio read once + magnitudes written once = 1 590 084 B per clip),
           with the C oracle's STFT timed beside it.
@@ -118,6 +121,11 @@ def cpu_baseline(sd_np, budget_s: float = 12.0):
 
 
 def lib_digest() -> str:
+    """Code digest of the library this process runs.  A variant picked with ADN_LIBADN_PATH (tools/variant_bench.sh) is not the
+    in-tree build: it reports "variant:<file>" so that no profile of the production build is attached to it."""
+    variant = os.environ.get("ADN_LIBADN_PATH")
+    if variant:
+        return "variant:" + os.path.basename(variant)
     from audiodenoiser_amd import build as B
     return B.code_digest_of_built_library()
 
@@ -131,6 +139,8 @@ def tracked_traffic(kernel_key: str):
             rec = json.load(fh)
     except (OSError, ValueError):
         return None, "profiles/pmc_traffic.json missing"
+    if lib_digest().startswith("variant:"):
+        return None, "library variant (ADN_LIBADN_PATH): no PMC profile belongs to it"
     if rec.get("lib_digest") != lib_digest():
         return None, "profiles/pmc_traffic.json was taken with another build of libadn.so (digest differs)"
     ent = rec.get("kernels", {}).get(kernel_key)
@@ -568,11 +578,89 @@ def bench_latency(sd_np, dev, iters=30):
                 else:
                     os.environ[k] = v
 
-    res = {"what": "forward only (no loss), back-to-back calls on one stream, HIP events; default = the kernels of the "
-                   "headline metric; serving = ADN_WINO_TILE=2 ADN_WINO_SPLITK=1 (F(2x2,3x3) grid + split-K)",
-           "default": run({}), "serving": run({"ADN_WINO_TILE": "2", "ADN_WINO_SPLITK": "1"})}
+    res = {"what": "forward only (no loss), back-to-back calls on one stream, HIP events; default = no environment variable set: "
+                   "per launch, F(4x4,3x3) where its grid fills the chip, else F(2x2,3x3) (+ split-K); batch_invariant = "
+                   "ADN_BATCH_INVARIANT=1 (one kernel per layer by geometry: bit-equal clips across batch sizes; the default of "
+                   "rounds 1-3); serving = ADN_WINO_TILE=2 ADN_WINO_SPLITK=1 (F(2x2,3x3) + split-K everywhere)",
+           "default": run({}), "batch_invariant": run({"ADN_BATCH_INVARIANT": "1"}),
+           "serving": run({"ADN_WINO_TILE": "2", "ADN_WINO_SPLITK": "1"})}
     torch.cuda.empty_cache()
     return res
+
+
+def bench_e2e_config0(sd_np, dev, iters=30, with_cpu=True):
+    """BASELINE configs[0] end to end as ONE stream sequence (the reference's test.py:94-113 flow with create_test_dataset.py:35-41
+    in front): resident audio (3 s @ 44.1 kHz) -> adn_stft_mag_fit (STFT 1024/256 centred + the loader's fp16 round trip and
+    crop to 513x256) -> adn_unet_forward, at batch 1 and 64, HIP-event timed; the oracle chain (C STFT + loader rule + the
+    torch forward) timed on the host beside it."""
+    from audiodenoiser_amd.stft import prepare, stft_magnitude_fit
+    net = make_net(sd_np, dev, "f32")
+    prepare(dev, 1024)
+    out = {"what": "audio resident in HBM -> adn_stft_mag_fit -> adn_unet_forward on one stream (no host round trip), HIP events "
+                   "around the whole sequence; 132 300-sample clips, n_fft 1024, hop 256, centred, target 513x256"}
+    g = torch.Generator(device=dev).manual_seed(0)
+    with torch.no_grad():
+        for b in (1, 64):
+            audio = torch.rand((b, 132300), generator=g, device=dev) * 2 - 1
+            for _ in range(3):
+                y = net(stft_magnitude_fit(audio, (F_BINS, T_FRAMES), 1024, 256, True))
+            n_it = iters if b == 1 else max(5, iters // 3)
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            torch.cuda.synchronize(dev)
+            e0.record()
+            for _ in range(n_it):
+                x = stft_magnitude_fit(audio, (F_BINS, T_FRAMES), 1024, 256, True)
+            e1.record()
+            for _ in range(n_it):
+                y = net(stft_magnitude_fit(audio, (F_BINS, T_FRAMES), 1024, 256, True))
+            e2.record()
+            torch.cuda.synchronize(dev)
+            assert bool(torch.isfinite(y).all())
+            ms = e1.elapsed_time(e2) / n_it
+            out[f"b{b}"] = {"ms_per_clip_batch": round(ms, 4), "stft_fit_ms": round(e0.elapsed_time(e1) / n_it, 4),
+                            "clips_per_s": round(b / (ms * 1e-3), 1), "frames_per_s": round(b * T_FRAMES / (ms * 1e-3), 1)}
+            del audio, x, y
+    net._release()
+    if with_cpu:
+        import oracle
+        from oracle import unet_torch
+        share = host_cores()
+        oracle.set_num_threads(share)
+        torch.set_num_threads(min(share, 16))
+        sd = unet_torch.to_torch_state(sd_np)
+        clips = np.random.default_rng(0).uniform(-1, 1, (2, 132300)).astype(np.float32)
+
+        def chain(a):
+            mag = oracle.stft_mag(a, 1024, 256, True)
+            xs = np.stack([oracle.quantize_pad(m, (F_BINS, T_FRAMES)) for m in (mag if mag.ndim == 3 else mag[None])])[:, None]
+            return unet_torch.unet_forward(sd, torch.from_numpy(xs))
+        chain(clips[:1])
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < 6.0 and n < 8:
+            chain(clips[:1])
+            n += 1
+        el = (time.perf_counter() - t0) / n
+        out["cpu_baseline"] = {"value": round(1.0 / el, 3), "unit": "clips/s", "ms_per_clip": round(el * 1e3, 1), "cores": min(share, 16),
+                               "kind": "port", "sample": f"{n} single clips through oracle.stft_mag (C, OpenMP) + quantize_pad + "
+                                                         "oracle/unet_torch.py (oneDNN)"}
+    torch.cuda.empty_cache()
+    return out
+
+
+def per_gpu_reference():
+    """fp32_b256 of the last recorded N = 1 line (profiles/r04_bench.json) if it was taken with this very build: the one-GPU
+    figure at 256 clips per GPU that an N > 1 value is to be divided by (the N = 1 headline runs 64 clips)."""
+    path = os.path.join(ROOT, "profiles", "r04_bench.json")
+    try:
+        with open(path) as fh:
+            rec = json.load(fh)
+    except (OSError, ValueError):
+        return {"value": None, "note": "no recorded N = 1 line (profiles/r04_bench.json)"}
+    if rec.get("config", {}).get("lib_digest") != lib_digest()[:12] or "fp32_b256" not in rec:
+        return {"value": None, "note": "profiles/r04_bench.json was taken with another build or without fp32_b256"}
+    return {"value": rec["fp32_b256"]["value"], "unit": "frames/s", "batch_per_gpu": 256,
+            "source": "profiles/r04_bench.json fp32_b256 (N = 1, same library digest)"}
 
 
 def main() -> None:
@@ -585,7 +673,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the sub-benchmarks (stft = configs[2], f16 = configs[4], fp32_b256, b1)")
-    ap.add_argument("--extras", default="stft,f16,fp32_b256,b1,exact_f32",
+    ap.add_argument("--extras", default="stft,f16,fp32_b256,b1,exact_f32,e2e_config0",
                     help="which sub-benchmarks to run (comma list; tools/profile_bench.sh profiles with stft,f16 only, so that the "
                          "kernel statistics of the headline kernel are not mixed with other batch sizes)")
     ap.add_argument("--stft-steps", type=int, default=20)
@@ -656,6 +744,7 @@ def main() -> None:
         if rehearsal:
             out["data"] = "synthetic; REHEARSAL of the N > 1 path on one GPU (gloo, every rank on device 0): not a measurement"
         if world > 1:
+            out["config"]["per_gpu_reference"] = per_gpu_reference()
             out["config"]["compare_with"] = ("the N = 1 line's fp32_b256.value (the same 256 clips per GPU on one GPU); the N = 1 "
                                              "headline value is BASELINE configs[1] at 64 clips")
         del allv
@@ -675,6 +764,8 @@ def main() -> None:
                     out["b1"] = bench_latency(sd_np, dev)
                 if "exact_f32" in extras and convt_uses_split_bf16(False):
                     out["exact_f32"] = bench_exact_f32(sd_np, dev)
+                if "e2e_config0" in extras:
+                    out["e2e_config0"] = bench_e2e_config0(sd_np, dev, with_cpu=not args.no_cpu_baseline)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(sd_np)
         print(json.dumps(out), flush=True)

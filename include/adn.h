@@ -12,8 +12,12 @@
  *     (NULL = the null stream).  No torch / C++ types cross this boundary.
  *   - every function returns an int status (ADN_OK = 0); on failure adn_last_error() returns a thread-local
  *     message.  Nothing throws or aborts across the ABI.
- *   - work is enqueued on the caller's stream; no function synchronises the device except
- *     adn_unet_create / adn_unet_destroy (one-time weight upload / free).
+ *   - work is enqueued on the caller's stream.  The only calls that block or allocate: adn_unet_create / adn_unet_destroy
+ *     (one-time weight upload / free), adn_prepare, and the FIRST call per (device, n_fft) of an STFT-family entry point
+ *     (adn_stft_mag, adn_stft_mag_fit, adn_stft_complex, adn_istft, adn_griffin_lim) or per device of adn_perceptual_loss, which
+ *     builds a few KB of constant tables (window, twiddles, mel filters) with a blocking upload -- unless adn_prepare did so
+ *     before.  Such a cold call on a stream that is being captured enqueues nothing and returns ADN_ERR_INVALID (never a HIP
+ *     error): call adn_prepare(device, n_fft) before capturing.  adn_unet_forward never blocks or allocates.
  *   - ownership: the caller owns every buffer it passes (x, y, audio, out, workspace); a handle owns only
  *     its packed (BatchNorm-folded, re-laid-out) weights.
  *   - a handle is bound to one device and is not re-entrant: one forward at a time per handle.  Entry points that
@@ -50,6 +54,12 @@ typedef struct adn_unet adn_unet;
 int adn_version(void);
 const char *adn_last_error(void);
 int adn_device_count(int *count);
+/* Builds the constant tables the handle-free entry points need on `device`: the window / twiddle tables of `n_fft` (a power
+ * of two in [64, 4096]; 0 = none) and the mel filterbank of adn_perceptual_loss.  Synchronous (blocking upload), idempotent,
+ * thread-safe.  After it, every adn_stft_* / adn_istft / adn_griffin_lim call with that n_fft and adn_perceptual_loss only
+ * enqueue on the caller's stream, so they can be captured into a HIP graph (e.g. adn_stft_mag_fit + adn_unet_forward, the
+ * wav -> network path of the reference's test.py:94-113). */
+int adn_prepare(int device, int n_fft);
 
 /* U-Net forward: replaces UNet.forward (reference code/model.py:70-94) and everything it calls —
  * DoubleConvLayer (model.py:7-20), DownSampleLayer (model.py:23-32), UpSampleLayer (model.py:35-50). ----- */

@@ -500,9 +500,9 @@ def test_roofline_accounting():
         # blocks of rows 528-543 of the 32x32 tiles do no arithmetic); the 32x16 bottleneck runs in pair mode (two clips
         # per tile), exact fit (the rule of wino4_applicable in csrc/wino4_kernels.hip)
         w = executed_mfma_flops(l, "winograd")
-        assert winograd_tile(l) == 4 and l["flops"] / 4 <= w <= l["flops"] / 4 * 1.03
-        if l["h"] == 513:
-            assert w == 4.5 * l["cin"] * l["cout"] * 528 * 256
+        assert winograd_tile(l) == 4 and l["flops"] / 4 <= w <= l["flops"] / 4 * 1.07
+        if l["h"] == 513:      # pooling / fused-1x1 variants skip blocks outside the image (528 rows), the plain variant does not (544)
+            assert w == 4.5 * l["cin"] * l["cout"] * (544 if l["name"] == "up4.conv1(cat)" else 528) * 256
         if l["name"].startswith("bottleneck"):
             assert w * 4 == l["flops"]
         assert executed_mfma_flops(l, "winograd", "4") >= l["flops"] / 4

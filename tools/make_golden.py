@@ -20,6 +20,8 @@ What is frozen:
 * ``unet_{trained,heavy}_<F>x<T>.npz`` (``--only variants``) — the reference forward under two more seeded parameter sets
   (``audiodenoiser_amd.weights.make_state_dict_variant``: trained-like BatchNorm statistics / heavy-tailed weights) on the
   real-audio input above cropped to (F, T), two clips at scale 1 and 100.
+* ``loss_cases.npz`` (``--only loss``) — the reference's ``MultiScaleSTFTLoss`` (``code/loss.py:6-35``) and ``nn.L1Loss``
+  (``loss.py:75,86``) on three seeded (B, 1, F, T) pairs.  The mel term needs torchaudio (absent): not frozen, parity unpinned.
 """
 from __future__ import annotations
 
@@ -134,9 +136,48 @@ def weight_variants() -> None:
             print(f"wrote {path} ({os.path.getsize(path)} B): y mean {float(y.mean()):+.4g} std {float(y.std()):.4g}; max|tap|: " + ", ".join(line))
 
 
+LOSS_CASES = ((3, 40, 96), (2, 257, 188), (2, 513, 256))
+
+
+def loss_inputs(case: int, b: int, f: int, t: int):
+    """(pred, target) of loss golden `case`: hash-PRNG magnitudes, target = a different stream (losses of order 1)."""
+    pred = hash_uniform(21, f"loss_pred{case}", b * f * t).reshape(b, 1, f, t) * np.float32(3.0)
+    target = hash_uniform(22, f"loss_target{case}", b * f * t).reshape(b, 1, f, t) * np.float32(3.0)
+    return pred.astype(np.float32), target.astype(np.float32)
+
+
+def loss_cases() -> None:
+    """``loss_cases.npz``: the torch-only terms of the reference's ``CombinedPerceptualLoss`` (code/loss.py:6-35,86) from the
+    reference's own code.  ``loss.py:4`` imports torchaudio (absent here) at module level; an EMPTY placeholder module is
+    registered under that name solely so that ``import loss`` resolves.  Only ``loss.MultiScaleSTFTLoss()`` and
+    ``torch.nn.L1Loss()`` are instantiated — neither touches torchaudio.  ``MelSpectrogramLoss`` /
+    ``CombinedPerceptualLoss`` are NOT instantiated (they need the real library): the mel term stays parity unpinned."""
+    import types
+    if "torchaudio" not in sys.modules:
+        sys.modules["torchaudio"] = types.ModuleType("torchaudio")        # empty: any attribute access raises
+    import loss as ref_loss  # reference code/loss.py
+
+    stft_loss = ref_loss.MultiScaleSTFTLoss()
+    l1_loss = torch.nn.L1Loss()                                           # what CombinedPerceptualLoss.__init__ holds (loss.py:75)
+    rec = {"cases": np.array(LOSS_CASES)}
+    for ci, (b, f, t) in enumerate(LOSS_CASES):
+        pred, target = (torch.from_numpy(a) for a in loss_inputs(ci, b, f, t))
+        with torch.no_grad():
+            s = stft_loss(pred, target)
+            l1 = l1_loss(pred, target)
+        rec[f"case{ci}_stft"] = np.array(float(s), dtype=np.float64)
+        rec[f"case{ci}_l1"] = np.array(float(l1), dtype=np.float64)
+        print(f"loss case {ci} {(b, f, t)}: stft {float(s):.7f} l1 {float(l1):.7f}")
+    path = os.path.join(GOLDEN, "loss_cases.npz")
+    np.savez_compressed(path, **rec)
+    print("wrote", path)
+
+
 def main() -> None:
     if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "config0":
         return config0_real_audio()
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "loss":
+        return loss_cases()
     if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "variants":
         return weight_variants()
     import data_loader as ref_loader  # reference code/data_loader.py
@@ -203,6 +244,7 @@ def main() -> None:
     print("wrote", path)
     config0_real_audio()
     weight_variants()
+    loss_cases()
 
 
 if __name__ == "__main__":

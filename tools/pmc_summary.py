@@ -29,8 +29,9 @@ FAMILIES = {
     "wino_conv_dma_f32": lambda n: n.startswith("wino_conv_dma_f32"),
     "conv_mfma_f32": lambda n: n.startswith("conv_mfma<float") and ", 9, " in n,
     "conv_mfma_f16": lambda n: n.startswith(("conv_mfma<_Float16", "conv_dma<_Float16")) and ", 9, " in n,
-    "convt_f32": lambda n: n.startswith(("conv_mfma<float", "conv_dma<float")) and ", 1, 4, 2" in n,
-    "convt_f16": lambda n: n.startswith(("conv_mfma<_Float16", "conv_dma<_Float16")) and ", 1, 4, 2" in n,
+    # transposed convolutions: <T, TH = 8, BN = 128, WM = 2, WN = 2, TAPS = 1, ...> (split-bf16 form: conv_dma<float, 8, 128, 2, 2, 1, 2, 2, 3, 1>)
+    "convt_f32": lambda n: n.startswith(("conv_mfma<float", "conv_dma<float")) and ", 8, 128, 2, 2, 1, " in n,
+    "convt_f16": lambda n: n.startswith(("conv_mfma<_Float16", "conv_dma<_Float16")) and ", 8, 128, 2, 2, 1, " in n,
     "stft_wave_kernel": lambda n: n.startswith("stft_wave_kernel") and not n.rstrip().endswith("true>"),
     "stft_wave_kernel_fit": lambda n: n.startswith("stft_wave_kernel") and n.rstrip().endswith("true>"),
     "stft_fit_kernel": lambda n: n.startswith("stft_fit_kernel"),

@@ -4,7 +4,7 @@
 #     gpurun --timeout 1100 -- 'bash tools/profile_bench.sh r02'
 # The program after `--` is python3 itself (no wrappers: the profiler initialises the GPU before the program starts).
 set -eo pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG

@@ -1,19 +1,19 @@
 #!/bin/bash
 # Round-end validation on the GPU box: all -m gpu tests, smoke(), rocprof kernel stats + PMC (tools/profile_bench.sh),
-# default bench line, batch-256 line, parity report against the reference goldens.  Outputs under gpurun_out/ (r03_*).
+# default bench line, batch-256 line, parity report against the reference goldens.  Outputs under gpurun_out/ (r04_*).
 #     gpurun --timeout 1200 -- 'bash tools/round_end_run.sh'
 set -e
-python -m pytest tests -x -q -m gpu > gpurun_out/r03_pytest_gpu.log 2>&1 || { tail -20 gpurun_out/r03_pytest_gpu.log; exit 1; }
-tail -1 gpurun_out/r03_pytest_gpu.log
+python -m pytest tests -x -q -m gpu > gpurun_out/r04_pytest_gpu.log 2>&1 || { tail -20 gpurun_out/r04_pytest_gpu.log; exit 1; }
+tail -1 gpurun_out/r04_pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')"
-bash tools/profile_bench.sh r03 > gpurun_out/r03_profile.log 2>&1 || { tail -20 gpurun_out/r03_profile.log; exit 1; }
-tail -3 gpurun_out/r03_profile.log
-cp gpurun_out/prof_r03/summary/pmc_traffic.json profiles/pmc_traffic.json     # the bench line below reads the traffic of THIS build
-python bench.py > gpurun_out/r03_bench.json 2> gpurun_out/r03_bench.err
-python bench.py --batch-per-gpu 256 --steps 30 --no-extras --no-cpu-baseline > gpurun_out/r03_bench_b256.json 2>/dev/null
-(python tools/report_parity.py; ADN_WINO_TILE=2 python tools/report_parity.py | sed 's/^winograd /wino F(2,3)/'; ADN_CONV_ALGO=direct python tools/report_parity.py) > gpurun_out/r03_parity.txt 2>/dev/null
+bash tools/profile_bench.sh r04 > gpurun_out/r04_profile.log 2>&1 || { tail -20 gpurun_out/r04_profile.log; exit 1; }
+tail -3 gpurun_out/r04_profile.log
+cp gpurun_out/prof_r04/summary/pmc_traffic.json profiles/pmc_traffic.json     # the bench line below reads the traffic of THIS build
+python bench.py > gpurun_out/r04_bench.json 2> gpurun_out/r04_bench.err
+python bench.py --batch-per-gpu 256 --steps 30 --no-extras --no-cpu-baseline > gpurun_out/r04_bench_b256.json 2>/dev/null
+(python tools/report_parity.py; ADN_WINO_TILE=2 python tools/report_parity.py | sed 's/^winograd /wino F(2,3)/'; ADN_CONV_ALGO=direct python tools/report_parity.py) > gpurun_out/r04_parity.txt 2>/dev/null
 python -c "
 import json
-d=json.load(open('gpurun_out/r03_bench.json')); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['traffic'], d['stft']['ms_per_launch'], d['f16']['frames_per_s'], d['cpu_baseline']['value'])
-d=json.load(open('gpurun_out/r03_bench_b256.json')); print(d['value'], d['ms_per_step'])"
-cat gpurun_out/r03_parity.txt
+d=json.load(open('gpurun_out/r04_bench.json')); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['traffic'], d['stft']['ms_per_launch'], d['f16']['frames_per_s'], d['cpu_baseline']['value'])
+d=json.load(open('gpurun_out/r04_bench_b256.json')); print(d['value'], d['ms_per_step'])"
+cat gpurun_out/r04_parity.txt
