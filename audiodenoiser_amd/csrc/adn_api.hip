@@ -115,7 +115,11 @@ struct adn_unet {
     // differs in the last bits (both within 1e-4 of the reference).  ADN_BATCH_INVARIANT=1 when the handle is created pins one
     // kernel per layer by geometry alone: a clip's result is bit-identical whatever batch it is computed in.
     bool batch_invariant = false;
-    long auto_grid = 512;
+    // thresholds of the rule, in F(4x4,3x3) workgroups of the launch, calibrated on per-launch timings at batch 1-16
+    // (tools/small_grid_probe.py, profiles/r04_small_grid_probe.txt): F(2x2,3x3) + split-K wins by 20-70 % up to 128
+    // workgroups, is level at 160 and loses by 25-50 % from 240 on; the 64-channel full-resolution layers (8-chunk K loops,
+    // where the prologue and epilogue of the 32x32-tile kernel weigh most, and down1 can take the first convolution in) switch at 512
+    long auto_grid = 192, auto_grid64 = 512;
     size_t zeros_off = 0;          // 64 zero floats inside the packed buffer
 };
 
@@ -417,12 +421,14 @@ Algo choose_algo(const adn_unet *h, adn::ConvKind kind, const adn::ConvArgs &a)
         r.f4 = r.ksplit == 1 && f4_ok;
         return r;
     }
-    if (!f4_ok) return r;
-    if (h->batch_invariant || h->force_wino4 || wino4_grid(a) >= h->auto_grid) {
+    const bool automatic = !h->batch_invariant && !h->force_wino4;
+    const long thr = a.Cout <= 64 ? h->auto_grid64 : h->auto_grid;
+    if (f4_ok && (!automatic || wino4_grid(a) >= thr)) {
         r.f4 = true;
         return r;
     }
-    if (can_split) r.ksplit = adn::wino_ksplit(adn::wino_workgroups(a), a.nchunk);      // small grid: F(2x2,3x3), cut along K if needed
+    // F(2x2,3x3); small grids are cut along K where even its finer grid cannot fill the chip
+    if (automatic && can_split) r.ksplit = adn::wino_ksplit(adn::wino_workgroups(a), a.nchunk);
     return r;
 }
 
@@ -686,7 +692,8 @@ int adn_unet_create_ex(adn_unet **handle, int device, const float *const *t, int
     if (const char *sk = std::getenv("ADN_WINO_SPLITK")) h->allow_split = std::atoi(sk) != 0;
     if (const char *cs = std::getenv("ADN_CONVT_SPLIT")) h->convt_split = std::atoi(cs) != 0;
     if (const char *bi = std::getenv("ADN_BATCH_INVARIANT")) h->batch_invariant = std::atoi(bi) != 0;
-    if (const char *ag = std::getenv("ADN_AUTO_GRID")) h->auto_grid = std::atol(ag);      // tuning knob of the small-grid rule (0: never)
+    if (const char *ag = std::getenv("ADN_AUTO_GRID")) h->auto_grid = std::atol(ag);      // tuning knobs of the small-grid rule
+    if (const char *ag = std::getenv("ADN_AUTO_GRID64")) h->auto_grid64 = std::atol(ag);
     if (h->f16) h->convt_split = false;
     if (const char *wt = std::getenv("ADN_WINO_TILE")) {
         h->use_wino4 = std::atoi(wt) != 2;
