@@ -75,6 +75,7 @@ struct Conv3x3Layer {
     int Cin, Cout;
     size_t w_off, b_off;   // float offsets into the packed device buffer
     size_t w4_off;         // F(4x4,3x3) pack of the same weights (fp32 Winograd path), 0 = none
+    size_t w16_off;        // fp16 path: pack_conv16 form of the same weights (16x16x32 kernel), 0 = none
 };
 struct ConvTLayer {
     int Cin, Cout;
@@ -114,6 +115,9 @@ struct adn_unet {
     // (choose_algo below).  The choice then depends on the batch size, so the same clip computed alone or inside a large batch
     // differs in the last bits (both within 1e-4 of the reference).  ADN_BATCH_INVARIANT=1 when the handle is created pins one
     // kernel per layer by geometry alone: a clip's result is bit-identical whatever batch it is computed in.
+    // fp16 path, 3x3 layers: 0 = conv_dma<_Float16> (32x32x16 MFMA, rounds 1-3) everywhere, 1 = conv16_f16 (16x16x32 MFMA,
+    // persistent, LDS-resident weights for the 64 -> 64 layers) wherever it applies, 2 = per layer (ADN_F16_CONV=32 / 16 / unset)
+    int f16_conv = 2;
     bool batch_invariant = false;
     // thresholds of the rule, in F(4x4,3x3) workgroups of the launch, calibrated on per-launch timings at batch 1-16
     // (tools/small_grid_probe.py, profiles/r04_small_grid_probe.txt): F(2x2,3x3) + split-K wins by 20-70 % up to 128
@@ -162,6 +166,21 @@ void pack_conv3x3(const float *w /*(Cout,Cin,3,3)*/, const std::vector<float> &s
                                 dst[o++] = (T)(w[((size_t)co * Cin + ci) * 9 + tap] * scale[co]);
                             }
                         }
+}
+
+// fp16 weights for conv16_f16 (conv16_kernels.hip): [cout tile of 64][chunk of 32 channels][tap][cout block j of 16][k group g]
+// [cout % 16][8 halfs], input channel = chunk*32 + 8g + e: the W fragment of (tap, j) is 64 lanes x 16 bytes = 1 KB contiguous,
+// lane = 16 g + cout % 16.  BatchNorm scale folded.
+void pack_conv16(const float *w /*(Cout,Cin,3,3)*/, const std::vector<float> &scale, int Cin, int Cout, _Float16 *dst)
+{
+    const int nchunk = Cin / 32;
+    for (int co = 0; co < Cout; ++co)
+        for (int ci = 0; ci < Cin; ++ci) {
+            const int ct = co / 64, j = (co % 64) / 16, c16 = co % 16, ch = ci / 32, g = (ci % 32) / 8, e = ci % 8;
+            for (int tap = 0; tap < 9; ++tap)
+                dst[(((((size_t)ct * nchunk + ch) * 9 + tap) * 4 + j) * 64 + g * 16 + c16) * 8 + e] =
+                    (_Float16)(w[((size_t)co * Cin + ci) * 9 + tap] * scale[co]);
+        }
 }
 
 // Winograd F(2x2,3x3) weights U = G g G^T (double precision, BatchNorm scale folded), packed for wino_conv_f32:
@@ -368,7 +387,7 @@ adn::ConvArgs conv_args(const adn_unet *h, const Conv3x3Layer &L, adn::ConvKind 
     a.nchunk0 = C0 / g.KC;
     a.nchunk = (C0 + C1) / g.KC;
     a.wpk = h->dev + L.w_off;
-    a.wpk4 = (h->use_wino && h->use_wino4 && L.w4_off) ? h->dev + L.w4_off : nullptr;
+    a.wpk4 = (h->use_wino && h->use_wino4 && L.w4_off) ? h->dev + L.w4_off : (h->f16 && L.w16_off) ? h->dev + L.w16_off : nullptr;
     a.bias = h->dev + L.b_off;
     a.out = out;
     a.pool = pool;
@@ -432,8 +451,28 @@ Algo choose_algo(const adn_unet *h, adn::ConvKind kind, const adn::ConvArgs &a)
     return r;
 }
 
+// fp16 path: which 3x3 layers run conv16_f16.  Per-layer rule of the default mode: measured per launch at batch 256
+// (profiles/r04_f16_kernels.txt)
+bool f16_use_conv16(const adn_unet *h, adn::ConvKind kind, const adn::ConvArgs &a16)
+{
+    if (h->f16_conv == 0 || !adn::conv16_applicable(kind, a16)) return false;
+    if (h->f16_conv == 1) return true;
+    // per layer (profiles/r04_f16_kernels.txt): the 64 -> 64 layers (weights resident in LDS) and the layers whose K loop is short
+    // (<= 4 chunks of 32 channels) are 2-15 % faster on conv16_f16, except the pooling 128 -> 128 layer; on the long-K layers both
+    // kernels sit at the same copy-ingest limit and conv_dma's two workgroups per CU hide it slightly better (0-4 %)
+    const int cin = a16.s0.C + a16.s1.C;
+    return cin <= 128 && !(cin == 128 && a16.Cout == 128 && kind == adn::CONV3X3_RELU_POOL);
+}
+
 hipError_t launch_conv3(const adn_unet *h, adn::ConvKind kind, const adn::ConvArgs &a, float *partial, hipStream_t st)
 {
+    if (h->f16 && a.wpk4) {                              // wpk4 carries the pack_conv16 form on the fp16 path
+        adn::ConvArgs a16 = a;
+        a16.wpk = a.wpk4;
+        a16.nchunk0 = a.s0.C / 32;
+        a16.nchunk = (a.s0.C + a.s1.C) / 32;
+        if (f16_use_conv16(h, kind, a16)) return adn::launch_conv16(kind, a16, a.s0.C + a.s1.C == 64 && a.Cout == 64, st);
+    }
     if (!h->use_wino) return adn::launch_conv_mfma(kind, a, h->f16, st);
     adn::ConvArgs a2 = a;
     const Algo algo = choose_algo(h, kind, a);
@@ -692,6 +731,7 @@ int adn_unet_create_ex(adn_unet **handle, int device, const float *const *t, int
     if (const char *sk = std::getenv("ADN_WINO_SPLITK")) h->allow_split = std::atoi(sk) != 0;
     if (const char *cs = std::getenv("ADN_CONVT_SPLIT")) h->convt_split = std::atoi(cs) != 0;
     if (const char *bi = std::getenv("ADN_BATCH_INVARIANT")) h->batch_invariant = std::atoi(bi) != 0;
+    if (const char *fc = std::getenv("ADN_F16_CONV")) h->f16_conv = std::atoi(fc) == 32 ? 0 : std::atoi(fc) == 16 ? 1 : 2;
     if (const char *ag = std::getenv("ADN_AUTO_GRID")) h->auto_grid = std::atol(ag);      // tuning knobs of the small-grid rule
     if (const char *ag = std::getenv("ADN_AUTO_GRID64")) h->auto_grid64 = std::atol(ag);
     if (h->f16) h->convt_split = false;
@@ -716,6 +756,11 @@ int adn_unet_create_ex(adn_unet **handle, int device, const float *const *t, int
         L.Cin = Cin;
         L.Cout = Cout;
         L.w4_off = 0;
+        L.w16_off = 0;
+        if (h->f16 && h->f16_conv != 0 && Cin % 32 == 0 && Cout % 64 == 0) {
+            L.w16_off = reserve(((size_t)9 * Cin * Cout + 1) / 2);
+            pack_conv16(t[ti], scale, Cin, Cout, reinterpret_cast<_Float16 *>(host.data() + L.w16_off));
+        }
         if (h->use_wino) {
             L.w_off = reserve((size_t)16 * Cin * Cout);
             pack_wino3x3(t[ti], scale, Cin, Cout, h->wino_bn, host.data() + L.w_off);

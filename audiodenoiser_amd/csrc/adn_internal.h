@@ -131,6 +131,12 @@ long wino_workgroups(const ConvArgs &a);
 bool wino4_applicable(ConvKind kind, const ConvArgs &a, bool force);
 hipError_t launch_wino4_conv(ConvKind kind, const ConvArgs &a, hipStream_t st);
 
+// fp16 3x3 layers on v_mfma_f32_16x16x32_f16 (conv16_kernels.hip): 32 x 16-pixel tiles x 64 couts, 32-channel chunks (ConvArgs::
+// nchunk0 / nchunk count those), persistent workgroups, weights from ConvArgs::wpk in pack_conv16 layout; `resident`: the whole
+// weight tensor of a 64 -> 64 layer stays in LDS
+bool conv16_applicable(ConvKind kind, const ConvArgs &a);
+hipError_t launch_conv16(ConvKind kind, const ConvArgs &a, bool resident, hipStream_t st);
+
 // First layer: Conv2d(1 -> 64, 3x3, pad 1) + folded BN + ReLU, fp32 input, blocked-layout output.  w9x64: [tap][cout].
 hipError_t launch_conv_first(const float *x, const float *w9x64, const float *bias, void *out, bool f16,
                              int N, int H, int W, hipStream_t st);

@@ -1,0 +1,475 @@
+// fp16 3x3 convolution of the U-Net forward on v_mfma_f32_16x16x32_f16 (gfx950), BASELINE configs[4].
+//
+// Same role as conv_dma<_Float16, 32, 64, ...> (conv_kernels.hip) for the 3x3 layers of the reference's DoubleConvLayer
+// (/root/reference/code/model.py:7-20): conv3x3(pad 1) + folded BatchNorm + ReLU (+ MaxPool2d(2), + virtual F.pad / torch.cat of
+// the up path, + the fused 1x1 output convolution), channel-blocked fp16 in and out (C16, adn_internal.h).  What is different:
+//   * MFMA shape 16x16x32 instead of 32x32x16.  Under dense fp16 MFMA load the chip holds its clock down, and how far depends on
+//     the shape: an LDS-fed loop on random data sustains 1 563 TFLOP/s with 16x16x32 on 4x4 register tiles against 1 392 with
+//     32x32x16 on 2x2 tiles (tools/ubench/f16_shapes.hip, profiles/r04_ubench_f16_shapes.txt).  K = 32 per instruction means
+//     K chunks of 32 channels = two blocks of the C16 layout.
+//   * operands swapped -- D[cout][pixel] = W-fragment x X-fragment -- so a lane ends up with 4 consecutive output channels of one
+//     pixel: the epilogue stores 8 bytes per lane straight from the accumulators (a wave-instruction = 16 pixels x 32 bytes =
+//     512 contiguous bytes), no LDS staging, no epilogue barrier; the max-pool is in-lane (rows) + one DPP exchange (columns).
+//   * persistent workgroups, one per CU (8 waves): the work items (tile, cout tile) of a launch are walked by the resident
+//     workgroups, and the copies of an item's first chunk fly under the last chunk of the item before it.
+//   * WRES (layers with Cin = Cout = 64: down1's second conv, up4's second conv): the whole weight tensor (72 KB) is copied into
+//     LDS once per workgroup and only halos stream: 39 KB per 4 608 matrix-pipe clocks instead of 76.
+// Workgroup tile = 32 x 16 pixels x 64 couts; wave w owns tile rows 4w .. 4w+3 (four 16-pixel row blocks) x all 64 couts (four
+// 16-cout blocks): 16 accumulator tiles of 16x16 = 64 registers.  Per chunk and tap a wave reads 4 X-fragments and 4 W-fragments
+// (ds_read_b128, 1 KB each) for 16 MFMAs: 0.5 KB of LDS reads per MFMA, half the LDS peak.
+// LDS image of a chunk (x2, double buffered): halo = 2 blocks x (34 rows x 18 pixels x 32 bytes, padded to 1280 sixteen-byte
+// slots) + (streamed weights only) the chunk's slab [tap][cout block][k group][cout % 16][8 halfs] = 36 KB.
+#include "adn_internal.h"
+
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+namespace adn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int C16_NT = 512;                       // threads per workgroup
+constexpr int C16_TH = 32, C16_TW = 16;           // tile (pixels)
+constexpr int C16_PH = C16_TH + 2, C16_PW = C16_TW + 2;
+constexpr int C16_ROWB = C16_PW * 32;             // bytes of a halo row of one block (18 pixels x 32 bytes)
+constexpr int C16_BLK_USED = C16_PH * C16_PW * 2; // 16-byte slots of one block's halo (1224)
+constexpr int C16_BLK_SLOTS = 1280;               // ... padded to 20 wave copies
+constexpr int C16_HALO_SLOTS = 2 * C16_BLK_SLOTS; // two blocks = 32 channels
+constexpr int C16_W_SLOTS = 9 * 4 * 64;           // weight slab of a chunk: [tap][cout block][lane] x 16 bytes (36 KB)
+constexpr int C16_HPIECES = C16_HALO_SLOTS / 64 / 8;       // halo copies per wave and chunk (5)
+constexpr int C16_WPIECES = (C16_W_SLOTS / 64 + 7) / 8;    // weight copies per wave and chunk (5, the last half used)
+
+#ifndef C16_PPT
+#define C16_PPT 2                                 // copies issued per tap (from tap 0 on)
+#endif
+constexpr int C16_B_SLOTS = 64;                   // one wave copy: the 64 biases of the cout tile in the first 16 slots
+template <bool WRES> struct C16Lds {
+    static constexpr int IMG_SLOTS = WRES ? C16_HALO_SLOTS : C16_HALO_SLOTS + C16_W_SLOTS + C16_B_SLOTS;
+    static constexpr int RES_SLOTS = WRES ? 2 * C16_W_SLOTS + C16_B_SLOTS : 0;   // resident: weights of two chunks (Cin = 64) + biases
+    static constexpr size_t BYTES = (size_t)(RES_SLOTS + 2 * IMG_SLOTS) * 16;
+};
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int c16_xcd_remap(int b, int nwg)
+{
+    const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
+
+// One work item = (clip n, tile ty, tx, cout tile ct); items are numbered ct fastest, then tx, ty, n.
+struct C16Item {
+    int n, ty, tx, ct;
+};
+// (every field through readfirstlane: the item is wave-uniform by construction, and descriptors / scalar offsets built from it
+// must live in SGPRs -- a descriptor hipcc cannot prove uniform turns every copy into a waterfall loop)
+__device__ __forceinline__ C16Item c16_decode(const ConvArgs &p, int id)
+{
+    C16Item it;
+    id = __builtin_amdgcn_readfirstlane(id);
+    int q1;
+    if (p.pair) {                                  // (ConvArgs::pair reused as the item order) cout tile SLOWEST: every resident
+        // workgroup works on the same cout tile at the same time, so its weights (Cin x 64 x 9 halfs: at most 1.2 MB) stay in every
+        // XCD's L2 however far the workgroups drift apart, and only the halos stream from beyond it
+        const int ct = fastdiv(id, p.fdNcg.d, p.fdNcg.m);          // fdNcg = tiles per cout tile
+        it.ct = __builtin_amdgcn_readfirstlane(ct);
+        q1 = id - ct * (int)p.fdNcg.d;
+    } else {
+        q1 = fastdiv(id, p.fdGc.d, p.fdGc.m);
+        it.ct = __builtin_amdgcn_readfirstlane(id - q1 * p.nct);
+    }
+    const int q2 = fastdiv(q1, p.fdTx.d, p.fdTx.m);
+    it.tx = __builtin_amdgcn_readfirstlane(q1 - q2 * p.tilesX);
+    it.n = __builtin_amdgcn_readfirstlane(fastdiv(q2, p.fdTy.d, p.fdTy.m));
+    it.ty = __builtin_amdgcn_readfirstlane(q2 - it.n * p.tilesY);
+    return it;
+}
+
+// EPI: CONV3X3_RELU / CONV3X3_RELU_POOL / CONV3X3_RELU_DOT (adn_internal.h).  WRES: weights resident in LDS (nchunk <= 2, nct == 1).
+template <int EPI, bool WRES>
+__global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
+{
+    using L = C16Lds<WRES>;
+    constexpr int IMG_B = L::IMG_SLOTS * 16;                   // bytes per image
+    constexpr int RES_B = L::RES_SLOTS * 16;
+    constexpr int BIAS_OFF = (WRES ? 2 * C16_W_SLOTS : C16_HALO_SLOTS + C16_W_SLOTS) * 16;      // bias slots: resident region / image
+    extern __shared__ __attribute__((aligned(16))) char smem16[];
+    char *const img_base = smem16 + RES_B;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, l16 = lane & 15;
+
+    // items of this workgroup: positions first, first + gsz, ... of the item order (ct fastest, then tx, ty, n); the resident
+    // workgroups of one XCD hold neighbouring positions (speed only)
+    const int nitems = p.nwg_total;
+    const int gsz = (int)gridDim.x;
+    const int first = __builtin_amdgcn_readfirstlane(c16_xcd_remap((int)blockIdx.x, gsz));
+    const int cnt = first < nitems ? (nitems - first + gsz - 1) / gsz : 0;
+    if (cnt == 0) return;
+    const int nchunk = p.nchunk;
+    const int nsteps = cnt * nchunk;
+
+    // ---- fetch side: the item whose chunks are being copied runs one step ahead of the item being computed ----
+    int f_item = first, f_chunk = 0;
+    C16Item fi = c16_decode(p, f_item);
+    unsigned hcur[C16_HPIECES];                     // byte offset of this lane's 16 bytes inside a channel block of the source, per piece
+    // slot -> (row, pixel, half) of the halo is tile independent: piece k of wave w covers slots (8k + w) * 64 + lane
+    int prow[C16_HPIECES], ppx[C16_HPIECES];        // halo row / pixel of the slot (row < 0: pad slot)
+#pragma unroll
+    for (int k = 0; k < C16_HPIECES; ++k) {
+        const int s = ((8 * k + wave) * 64 + lane) % C16_BLK_SLOTS;
+        const int row = s / (2 * C16_PW), q = s - row * (2 * C16_PW);
+        prow[k] = s < C16_BLK_USED ? row : -1000;
+        ppx[k] = (q >> 1) | ((q & 1) << 16);        // pixel, half in bit 16
+    }
+    // descriptors are rebuilt from scalars at every use (two SALU operations) instead of being carried through the loop
+    const char *hbase = nullptr;                    // image of clip n in the current source
+    unsigned himg_bytes = 0, hblk_bytes = 0;        // bytes of that image / of one of its channel blocks (H * W * 32)
+    auto plan = [&](const ConvSrc &s, const C16Item &it) {
+        const int gy0 = it.ty * C16_TH - 1 - s.offY, gx0 = it.tx * C16_TW - 1 - s.offX;
+#pragma unroll
+        for (int k = 0; k < C16_HPIECES; ++k) {
+            const int y = gy0 + prow[k], x = gx0 + (ppx[k] & 0xffff);
+            const unsigned off = (unsigned)((y * s.W + x) * 32 + (ppx[k] >> 16) * 16);
+            hcur[k] = (y >= 0 && y < s.H && x >= 0 && x < s.W) ? off : ADN_DMA_OOB;
+        }
+        himg_bytes = (unsigned)(s.C * s.H * s.W) * 2u;
+        hblk_bytes = (unsigned)(s.H * s.W) * 32u;
+        hbase = static_cast<const char *>(s.ptr) + (size_t)it.n * himg_bytes;
+    };
+    plan(p.s0, fi);
+    const __amdgpu_buffer_rsrc_t wrs = dma_rsrc(p.wpk, (unsigned)((size_t)p.nct * nchunk * C16_W_SLOTS * 16));
+    const __amdgpu_buffer_rsrc_t brs = dma_rsrc(p.bias, (unsigned)p.Cout * 4u);
+    // piece q (0 .. NPIECE-1) of the fetch step into image `buf`
+    auto fetch_piece = [&](int q, int buf) {
+        char *img = img_base + buf * IMG_B;
+        if (q < C16_HPIECES) {
+            const int pi = 8 * q + wave;                             // wave-uniform piece index (0 .. 39)
+            const int blk = pi >= 20 ? 1 : 0;
+            const int cl = f_chunk < p.nchunk0 ? f_chunk : f_chunk - p.nchunk0;      // chunk inside the current source
+            const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((2 * cl + blk) * (int)hblk_bytes);
+            // (pointer and size through readfirstlane: they are wave-uniform, but hipcc keeps loop-carried scalars in VGPRs when it
+            // runs short of SGPRs, and a descriptor in VGPRs makes every copy a waterfall loop)
+            const unsigned long long hb = reinterpret_cast<unsigned long long>(hbase);
+            const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)hb);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(hb >> 32));
+            const void *ub = reinterpret_cast<const void *>(((unsigned long long)hi << 32) | lo);
+            dma16_buf(dma_rsrc(ub, (unsigned)__builtin_amdgcn_readfirstlane((int)himg_bytes)), hcur[q], soff,
+                      reinterpret_cast<float *>(img + pi * 1024));
+        } else if (!WRES) {
+            const int pi = 8 * (q - C16_HPIECES) + wave;             // 0 .. 39: the slab has 36 pieces, piece 36 carries the biases
+            if (pi < C16_W_SLOTS / 64) {
+                const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((fi.ct * nchunk + f_chunk) * (C16_W_SLOTS * 16) + pi * 1024);
+                dma16_buf(wrs, lane * 16, soff, reinterpret_cast<float *>(img + C16_HALO_SLOTS * 16 + pi * 1024));
+            } else if (pi == C16_W_SLOTS / 64 && f_chunk == 0) {
+                dma16_buf(brs, lane < 16 ? lane * 16 : ADN_DMA_OOB, (unsigned)__builtin_amdgcn_readfirstlane(fi.ct * 256),
+                          reinterpret_cast<float *>(img + BIAS_OFF));
+            }
+        }
+    };
+    auto fetch_advance = [&]() {                    // after the last piece of a step: next chunk, or the next item's first
+        if (++f_chunk == nchunk) {
+            f_chunk = 0;
+            f_item += gsz;
+            if (f_item < nitems) {
+                fi = c16_decode(p, f_item);
+                plan(p.s0, fi);
+            }
+        } else if (f_chunk == p.nchunk0) {
+            plan(p.s1, fi);                         // virtual concat: the second source (with its pad offset)
+        }
+    };
+    constexpr int NPIECE = C16_HPIECES + (WRES ? 0 : C16_WPIECES);
+
+    // ---- prologue: resident weights + biases, first step's copies ----
+    if constexpr (WRES) {
+#pragma unroll
+        for (int k = 0; k < (2 * C16_W_SLOTS / 64 + 7) / 8; ++k) {
+            const int pi = 8 * k + wave;
+            if (pi < nchunk * (C16_W_SLOTS / 64)) dma16_buf(wrs, lane * 16, (unsigned)pi * 1024u, reinterpret_cast<float *>(smem16 + pi * 1024));
+        }
+        if (wave == 0) dma16_buf(brs, lane < 16 ? lane * 16 : ADN_DMA_OOB, 0u, reinterpret_cast<float *>(smem16 + BIAS_OFF));
+    }
+#pragma unroll
+    for (int q = 0; q < NPIECE; ++q) fetch_piece(q, 0);
+    fetch_advance();
+
+    // ---- compute side ----
+    int c_item = first, c_chunk = 0;
+    C16Item ci = c16_decode(p, c_item);
+    f32x4 acc[4][4];                                // [pixel row block i][cout block j]: lane = (pixel l16, couts 4g .. 4g+3)
+
+    // LDS read bases (bytes): X fragment of row block i, tap (dy, dx): lane (pixel l16, k group g) reads channels 8g .. 8g+7 of
+    // the chunk = half (g & 1) of block (g >> 1) at pixel (4 wave + i + dy, l16 + dx)
+    const int x_lane = (g >> 1) * (C16_BLK_SLOTS * 16) + (g & 1) * 16 + l16 * 32 + wave * 4 * C16_ROWB;
+    const int w_lane = lane * 16;
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+#ifdef ADN_EXPERIMENTS
+    // step timeline (ADN_C16_TIMELINE, p.dbg != nullptr): per wave, clocks summed over the steps: start -> last MFMA issued ->
+    // own copies landed (vmcnt) -> barrier passed; launch_c16 prints the averages
+    const bool tl_on = p.dbg != nullptr;
+    unsigned long long tl_c = 0, tl_sum[3] = {0, 0, 0}, tl_0 = tl_on ? __builtin_amdgcn_s_memtime() : 0, tl_first = tl_0;
+#endif
+#pragma clang loop unroll(disable)
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        const bool more = s + 1 < nsteps;
+        const char *img = img_base + buf * IMG_B;
+        const char *wimg = WRES ? smem16 + c_chunk * (C16_W_SLOTS * 16) : img + C16_HALO_SLOTS * 16;
+        if (c_chunk == 0) {
+            // folded-BN bias rides in the accumulators (the copies staged it in LDS): no bias load or add in the epilogue
+            const char *bl = (WRES ? smem16 : img) + BIAS_OFF + g * 16;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 b = *reinterpret_cast<const f32x4 *>(bl + j * 64);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i][j] = b;
+            }
+        }
+        // fragments of a tap are read one tap ahead of its MFMAs
+        f16x8 xf[2][4], wf[2][4];
+        auto load_tap = [&](int tap, int slot) {
+            const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                wf[slot][j] = *reinterpret_cast<const f16x8 *>(wimg + w_lane + (tap * 4 + j) * 1024);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                xf[slot][i] = *reinterpret_cast<const f16x8 *>(img + x_lane + (i + dy) * C16_ROWB + dx * 32);
+        };
+        load_tap(0, 0);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap < 8) load_tap(tap + 1, (tap + 1) & 1);
+            // the next step's copies go out between the first taps' MFMA groups (C16_PPT per tap): the last one has the rest of
+            // the step to land before the wait at its end
+            if (more) {
+#pragma unroll
+                for (int q = tap * C16_PPT; q < (tap + 1) * C16_PPT; ++q)
+                    if (q < NPIECE) fetch_piece(q, buf ^ 1);
+            }
+#ifdef ADN_EXPERIMENTS
+            if (tap == 8 && tl_on) tl_c = __builtin_amdgcn_s_memtime();
+#endif
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tap & 1][j], xf[tap & 1][i], acc[i][j], 0, 0, 0);
+        }
+        if (more) fetch_advance();
+
+        if (++c_chunk == nchunk) {
+            // ---- epilogue of the item: ReLU, 8-byte stores straight from the accumulators, through buffer descriptors (a lane
+            // outside the image stores out of range = nowhere): no branches, a fixed number of stores, so the wait below can
+            // leave exactly them in flight ----
+            c_chunk = 0;
+            const int gx = ci.tx * C16_TW + l16;
+            const int gyb = ci.ty * C16_TH + wave * 4;
+            if constexpr (EPI == CONV3X3_RELU_DOT) {
+                // fused last layer (model.py:91,93): y[px] = bias1x1 + sum over the 64 channels of w1x1[c] * ReLU(conv[c][px]);
+                // a lane adds its 16 channels, the four k groups of a pixel meet by two exchanges (fixed order)
+                const float *dw = p.dotw + 4 * g;
+                float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 w = *reinterpret_cast<const f32x4 *>(dw + 16 * j);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) part[i] += w[r] * fmaxf(acc[i][j][r], 0.f);
+                }
+                const __amdgpu_buffer_rsrc_t yrs = dma_rsrc(p.dot_out + (size_t)ci.n * p.H * p.W, (unsigned)(p.H * p.W) * 4u);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v = part[i];
+                    v += __shfl_xor(v, 16, 64);
+                    v += __shfl_xor(v, 32, 64);
+                    const unsigned off = (g == 0 && gyb + i < p.H && gx < p.W) ? (unsigned)(((gyb + i) * p.W + gx) * 4) : ADN_DMA_OOB;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v + p.dot_bias), yrs, off, 0, 0);
+                }
+            } else {
+                const unsigned HWb = (unsigned)(p.H * p.W) * 32u;          // bytes of one channel block of the output
+                const __amdgpu_buffer_rsrc_t ors = dma_rsrc(static_cast<const char *>(p.out) + (size_t)ci.n * p.Cout * p.H * p.W * 2,
+                                                            (unsigned)(p.Cout * p.H * p.W) * 2u);
+                const int Hp = p.H >> 1, Wp = p.W >> 1;
+                const unsigned HWpb = (unsigned)(Hp * Wp) * 32u;
+                const __amdgpu_buffer_rsrc_t prs = dma_rsrc(EPI == CONV3X3_RELU_POOL ? static_cast<const char *>(p.pool) + (size_t)ci.n * p.Cout * Hp * Wp * 2 : nullptr,
+                                                            EPI == CONV3X3_RELU_POOL ? (unsigned)(p.Cout * Hp * Wp) * 2u : 0u);
+                unsigned ooff[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    ooff[i] = (gyb + i < p.H && gx < p.W) ? (unsigned)(((gyb + i) * p.W + gx) * 32 + g * 8) : ADN_DMA_OOB;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned cb = (unsigned)__builtin_amdgcn_readfirstlane((ci.ct * 4 + j) * (int)HWb);
+                    f32x4 v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[i][r] = fmaxf(acc[i][j][r], 0.f);
+                        const f16x4 hv = {(_Float16)v[i][0], (_Float16)v[i][1], (_Float16)v[i][2], (_Float16)v[i][3]};
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hv), ors, ooff[i], cb, 0);
+                    }
+                    if constexpr (EPI == CONV3X3_RELU_POOL) {
+                        // MaxPool2d(2), floor mode: rows (2a, 2a+1) are this lane's row blocks, columns (2x, 2x+1) neighbouring lanes
+                        const unsigned cbp = (unsigned)__builtin_amdgcn_readfirstlane((ci.ct * 4 + j) * (int)HWpb);
+#pragma unroll
+                        for (int a = 0; a < 2; ++a) {
+                            f32x4 m;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float t = fmaxf(v[2 * a][r], v[2 * a + 1][r]);
+                                m[r] = fmaxf(t, __shfl_xor(t, 1, 64));
+                            }
+                            const int py = (gyb >> 1) + a, px = gx >> 1;
+                            const unsigned poff = (!(l16 & 1) && py < Hp && px < Wp) ? (unsigned)((py * Wp + px) * 32 + g * 8) : ADN_DMA_OOB;
+                            const f16x4 hm = {(_Float16)m[0], (_Float16)m[1], (_Float16)m[2], (_Float16)m[3]};
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hm), prs, poff, cbp, 0);
+                        }
+                    }
+                }
+            }
+            c_item += gsz;
+            if (c_item < nitems) ci = c16_decode(p, c_item);
+            // this wave's copies of the next step have landed; its NST stores (younger than every copy) may still be in flight
+            constexpr int NST = EPI == CONV3X3_RELU_DOT ? 4 : EPI == CONV3X3_RELU_POOL ? 24 : 16;
+            // (s_barrier as inline asm: __syncthreads() carries a fence that hipcc lowers to s_waitcnt vmcnt(0) -- it would wait
+            // for the stores.  Every LDS read of this step has been consumed by an MFMA, and the copies into the other image were
+            // awaited just above, so the bare barrier orders everything the next step relies on.)
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (NST == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if constexpr (NST == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+#ifdef ADN_EXPERIMENTS
+        unsigned long long tl_w = 0;
+        if (tl_on) tl_w = __builtin_amdgcn_s_memtime();
+#endif
+        // all waves: image `buf` is free, image `buf ^ 1` complete
+        asm volatile("s_barrier" ::: "memory");
+#ifdef ADN_EXPERIMENTS
+        if (tl_on) {
+            const unsigned long long tl_b = __builtin_amdgcn_s_memtime();
+            tl_sum[0] += tl_c - tl_0; tl_sum[1] += tl_w - tl_c; tl_sum[2] += tl_b - tl_w;
+            tl_0 = tl_b;
+        }
+#endif
+    }
+#ifdef ADN_EXPERIMENTS
+    if (tl_on && lane == 0) {
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(p.dbg) + ((size_t)blockIdx.x * 8 + wave) * 8;
+        o[0] = tl_sum[0]; o[1] = tl_sum[1]; o[2] = tl_sum[2]; o[3] = (unsigned long long)nsteps; o[4] = tl_0 - tl_first;
+    }
+#endif
+}
+
+template <int EPI, bool WRES>
+hipError_t launch_c16(const ConvArgs &a, hipStream_t st)
+{
+    using L = C16Lds<WRES>;
+    ConvArgs a2 = a;
+    a2.tilesY = (a.H + C16_TH - 1) / C16_TH;
+    a2.tilesX = (a.W + C16_TW - 1) / C16_TW;
+    a2.nct = a.Cout / 64;
+    const long nitems = (long)a.N * a2.tilesY * a2.tilesX * a2.nct;
+    long maxd = a2.nct > a2.tilesX ? (a2.nct > a2.tilesY ? a2.nct : a2.tilesY) : (a2.tilesX > a2.tilesY ? a2.tilesX : a2.tilesY);
+    {
+        static const int order = []() { const char *e = std::getenv("ADN_C16_ORDER"); return e ? std::atoi(e) : 0; }();
+        a2.pair = (order && a2.nct > 1) ? 1 : 0;   // item order: 1 = cout tile slowest (c16_decode); measured 5-8 % slower on the deep layers
+    }
+    if (a2.pair && nitems / a2.nct > maxd) maxd = nitems / a2.nct;
+    if (nitems <= 0 || nitems > 0x7fffffffL || (unsigned long long)nitems * (unsigned long long)maxd >= 0x100000000ull) return hipErrorInvalidValue;
+    a2.fdGc = make_fastdiv((unsigned)a2.nct);
+    a2.fdNcg = make_fastdiv((unsigned)(nitems / a2.nct));
+    a2.fdTx = make_fastdiv((unsigned)a2.tilesX);
+    a2.fdTy = make_fastdiv((unsigned)a2.tilesY);
+    a2.nwg_total = (int)nitems;
+    static std::atomic<int> cus{0};                   // (one device model per process: gfx950 only, checked at handle creation)
+    int c = cus.load(std::memory_order_relaxed);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
+    if (c == 0) {
+        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c < 8) return hipErrorInvalidDevice;
+        c &= ~7;                                       // whole slots on each of the 8 XCDs
+        cus.store(c, std::memory_order_relaxed);
+    }
+    long grid = nitems < c ? ((nitems + 7) & ~7L) : c;   // one resident workgroup per CU walks the items
+    auto kern = conv16_f16<EPI, WRES>;
+    static std::atomic<unsigned long long> attr_mask{0};
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(attr_mask.load(std::memory_order_acquire) & bit)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES);
+        if (e != hipSuccess) return e;
+        attr_mask.fetch_or(bit, std::memory_order_release);
+    }
+#ifdef ADN_EXPERIMENTS
+    static const bool timeline = std::getenv("ADN_C16_TIMELINE") != nullptr;
+    if (timeline) {
+        const size_t bytes = (size_t)grid * 8 * 8 * sizeof(unsigned long long);
+        if (hipMalloc(&a2.dbg, bytes) != hipSuccess) return hipErrorOutOfMemory;
+        (void)hipMemset(a2.dbg, 0, bytes);
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C16_NT), L::BYTES, st, a2);
+        (void)hipStreamSynchronize(st);
+        std::vector<unsigned long long> hb(bytes / 8);
+        (void)hipMemcpy(hb.data(), a2.dbg, bytes, hipMemcpyDeviceToHost);
+        (void)hipFree(a2.dbg);
+        double sum[3] = {0, 0, 0}, steps = 0, span = 0, byw[8][3] = {};
+        for (long b = 0; b < grid * 8; ++b) {
+            for (int k = 0; k < 3; ++k) { sum[k] += (double)hb[b * 8 + k]; byw[b & 7][k] += (double)hb[b * 8 + k]; }
+            steps += (double)hb[b * 8 + 3];
+            span += (double)hb[b * 8 + 4];
+        }
+        if (steps < 1) steps = 1;
+        std::fprintf(stderr, "[c16 timeline EPI %d WRES %d] H %d W %d Cin %d Cout %d nchunk %d: per step and wave: issue + MFMAs %.0f  copies awaited %.0f  "
+                             "barrier %.0f  (sum %.0f clocks; ideal 4608);  by wave (issue / wait / barrier):", EPI, (int)WRES, a2.H, a2.W,
+                     a2.s0.C + a2.s1.C, a2.Cout, a2.nchunk, sum[0] / steps, sum[1] / steps, sum[2] / steps, span / steps);
+        for (int w = 0; w < 8; ++w) std::fprintf(stderr, " w%d %.0f/%.0f/%.0f", w, byw[w][0] / steps * 8, byw[w][1] / steps * 8, byw[w][2] / steps * 8);
+        std::fprintf(stderr, "\n");
+        return hipGetLastError();
+    }
+#endif
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C16_NT), L::BYTES, st, a2);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// Layers the 16x16x32 kernel serves: Cin (every source) a multiple of 32, Cout a multiple of 64.  `resident`: the whole weight
+// tensor fits LDS next to two halo images (Cin = Cout = 64).
+bool conv16_applicable(ConvKind kind, const ConvArgs &a)
+{
+    if (kind != CONV3X3_RELU && kind != CONV3X3_RELU_POOL && kind != CONV3X3_RELU_DOT) return false;
+    if ((a.s0.C & 31) || (a.s1.C & 31) || (a.Cout & 63) || a.firstw) return false;
+    if (kind == CONV3X3_RELU_DOT && (a.Cout != 64 || !a.dotw || !a.dot_out)) return false;
+    return true;
+}
+
+hipError_t launch_conv16(ConvKind kind, const ConvArgs &a, bool resident, hipStream_t st)
+{
+    if (!conv16_applicable(kind, a)) return hipErrorInvalidValue;
+    if (resident && (a.nchunk > 2 || a.Cout != 64)) return hipErrorInvalidValue;
+    if (resident) {
+        if (kind == CONV3X3_RELU_DOT) return launch_c16<CONV3X3_RELU_DOT, true>(a, st);
+        if (kind == CONV3X3_RELU_POOL) return launch_c16<CONV3X3_RELU_POOL, true>(a, st);
+        return launch_c16<CONV3X3_RELU, true>(a, st);
+    }
+    if (kind == CONV3X3_RELU_DOT) return launch_c16<CONV3X3_RELU_DOT, false>(a, st);
+    if (kind == CONV3X3_RELU_POOL) return launch_c16<CONV3X3_RELU_POOL, false>(a, st);
+    return launch_c16<CONV3X3_RELU, false>(a, st);
+}
+
+}  // namespace adn

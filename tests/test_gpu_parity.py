@@ -680,20 +680,39 @@ def test_convt_split_bf16_matches_exact_fp32_form(dev, weights_np, golden_dir, m
 
 
 # ---------------------------------------------------------------------------------------------- fp16 path
-def test_fp16_path_within_1e2_of_fp32_reference(dev, weights_np, golden_dir):
+@pytest.mark.parametrize("conv", ["default", "16", "32"])
+def test_fp16_path_within_1e2_of_fp32_reference(dev, weights_np, golden_dir, conv, monkeypatch):
     """BASELINE configs[4]: fp16 storage + fp16 MFMA (fp32 accumulate); outputs within 1e-2 (relative to max|ref|)
-    of the fp32 reference goldens, on every golden shape, and block outputs within 1e-2 of their rms."""
+    of the fp32 reference goldens, on every golden shape, and block outputs within 1e-2 of their rms.  Both 3x3 kernel
+    families: conv16_f16 (16x16x32 MFMA, ADN_F16_CONV=16 forces it wherever it applies), conv_dma<_Float16> (32x32x16,
+    ADN_F16_CONV=32) and the per-layer default."""
     from audiodenoiser_amd.model import UNet
     from audiodenoiser_amd.weights import make_input
+    monkeypatch.delenv("ADN_F16_CONV", raising=False)
+    if conv != "default":
+        monkeypatch.setenv("ADN_F16_CONV", conv)
     m = UNet(1, 1)
     m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in weights_np.items()}, strict=True)
     m = m.to(dev).eval().set_compute_dtype("f16")
-    for (n, f, t) in GOLDEN_SHAPES:
+    with torch.no_grad():
+        m(torch.zeros((1, 1, 16, 16), device=dev))               # the handle (and its switches) is created at the first forward
+    monkeypatch.delenv("ADN_F16_CONV", raising=False)
+    for (n, f, t) in GOLDEN_SHAPES + ((3, 20, 36), (2, 31, 16)):
+        if (f, t) not in [(s[1], s[2]) for s in GOLDEN_SHAPES]:
+            import oracle
+            x = make_input(21, n, f, t)
+            ref = oracle.unet_forward(weights_np, x, acc64=True)
+            with torch.no_grad():
+                y, y_taps = m(torch.from_numpy(x).to(dev)), m(torch.from_numpy(x).to(dev), return_taps=True)[0]
+            assert _rel(y.cpu().numpy(), ref) <= 1e-2 and _rel(y_taps.cpu().numpy(), ref) <= 1e-2, (f, t)
+            continue
         g = np.load(os.path.join(golden_dir, f"unet_{f}x{t}.npz"))
         with torch.no_grad():
             y, taps = m(torch.from_numpy(make_input(7, n, f, t)).to(dev), return_taps=True)
+            y_plain = m(torch.from_numpy(make_input(7, n, f, t)).to(dev))         # production sequence: fused 1x1 tail
         assert y.dtype == torch.float32
         assert _rel(y.cpu().numpy(), g["y"]) <= 1e-2, (f, t)
+        assert _rel(y_plain.cpu().numpy(), g["y"]) <= 1e-2, (f, t)
         for name, tp in taps.items():
             a = tp.cpu().numpy().astype(np.float64).ravel()
             s_, sa, sq, cnt = g[f"{name}_stats"]
