@@ -118,6 +118,7 @@ struct adn_unet {
     // fp16 path, 3x3 layers: 0 = conv_dma<_Float16> (32x32x16 MFMA, rounds 1-3) everywhere, 1 = conv16_f16 (16x16x32 MFMA,
     // persistent, LDS-resident weights for the 64 -> 64 layers) wherever it applies, 2 = per layer (ADN_F16_CONV=32 / 16 / unset)
     int f16_conv = 2;
+    bool f16_fuse_first = true;    // ADN_F16_FIRST=0: Conv2d(1 -> 64) as its own launch (conv_first_kernel) on the fp16 path (A/B runs)
     bool batch_invariant = false;
     // thresholds of the rule, in F(4x4,3x3) workgroups of the launch, calibrated on per-launch timings at batch 1-16
     // (tools/small_grid_probe.py, profiles/r04_small_grid_probe.txt): F(2x2,3x3) + split-K wins by 20-70 % up to 128
@@ -457,11 +458,12 @@ bool f16_use_conv16(const adn_unet *h, adn::ConvKind kind, const adn::ConvArgs &
 {
     if (h->f16_conv == 0 || !adn::conv16_applicable(kind, a16)) return false;
     if (h->f16_conv == 1) return true;
-    // per layer (profiles/r04_f16_kernels.txt): the 64 -> 64 layers (weights resident in LDS) and the layers whose K loop is short
-    // (<= 4 chunks of 32 channels) are 2-15 % faster on conv16_f16, except the pooling 128 -> 128 layer; on the long-K layers both
-    // kernels sit at the same copy-ingest limit and conv_dma's two workgroups per CU hide it slightly better (0-4 %)
+    // per layer (profiles/r04_f16_kernels.txt): the layers fed by 64 channels -- the two 64 -> 64 layers (weights resident in LDS)
+    // and down2's first conv -- are 10-18 % faster on conv16_f16; from 128 input channels on both kernels sit at the same
+    // copy-ingest limit (within the +-3 % between boxes) and conv_dma's two workgroups per CU hide it slightly better
     const int cin = a16.s0.C + a16.s1.C;
-    return cin <= 128 && !(cin == 128 && a16.Cout == 128 && kind == adn::CONV3X3_RELU_POOL);
+    (void)kind;
+    return cin <= 64;
 }
 
 hipError_t launch_conv3(const adn_unet *h, adn::ConvKind kind, const adn::ConvArgs &a, float *partial, hipStream_t st)
@@ -471,6 +473,10 @@ hipError_t launch_conv3(const adn_unet *h, adn::ConvKind kind, const adn::ConvAr
         a16.wpk = a.wpk4;
         a16.nchunk0 = a.s0.C / 32;
         a16.nchunk = (a.s0.C + a.s1.C) / 32;
+        if (a.firstw) {                                  // fused first layer: the 64 input channels are computed inside the kernel
+            a16.nchunk0 = a16.nchunk = 2;
+            return adn::launch_conv16(kind, a16, true, st);
+        }
         if (f16_use_conv16(h, kind, a16)) return adn::launch_conv16(kind, a16, a.s0.C + a.s1.C == 64 && a.Cout == 64, st);
     }
     if (!h->use_wino) return adn::launch_conv_mfma(kind, a, h->f16, st);
@@ -529,6 +535,8 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
         const Algo algo = choose_algo(h, adn::CONV3X3_RELU_POOL, probe);
         if (algo.f4 || algo.ksplit > 1) fused_first = false;
     }
+    // fp16 path: the first layer is computed inside conv16_f16's halo stage of down1's second conv (conv16_kernels.hip, FIRST)
+    if (f16 && h->f16_conv != 0 && h->f16_fuse_first && h->c3[0].w16_off) fused_first = true;
     ADN_MARK();
     if (!fused_first)
         ADN_HIP(adn::launch_conv_first(x, h->dev + h->first_w, h->dev + h->first_b, tA, f16, N, p.H[0], p.W[0], st));
@@ -731,6 +739,7 @@ int adn_unet_create_ex(adn_unet **handle, int device, const float *const *t, int
     if (const char *sk = std::getenv("ADN_WINO_SPLITK")) h->allow_split = std::atoi(sk) != 0;
     if (const char *cs = std::getenv("ADN_CONVT_SPLIT")) h->convt_split = std::atoi(cs) != 0;
     if (const char *bi = std::getenv("ADN_BATCH_INVARIANT")) h->batch_invariant = std::atoi(bi) != 0;
+    if (const char *ff = std::getenv("ADN_F16_FIRST")) h->f16_fuse_first = std::atoi(ff) != 0;
     if (const char *fc = std::getenv("ADN_F16_CONV")) h->f16_conv = std::atoi(fc) == 32 ? 0 : std::atoi(fc) == 16 ? 1 : 2;
     if (const char *ag = std::getenv("ADN_AUTO_GRID")) h->auto_grid = std::atol(ag);      // tuning knobs of the small-grid rule
     if (const char *ag = std::getenv("ADN_AUTO_GRID64")) h->auto_grid64 = std::atol(ag);

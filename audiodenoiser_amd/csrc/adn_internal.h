@@ -40,6 +40,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t dma_rsrc(const void *base, uns
 }
 #endif
 
+#ifdef __HIPCC__
+// ReLU that keeps a NaN a NaN (fmaxf / v_max_f32 is IEEE maxNum: it returns the other operand): the fp16 path and the direct
+// kernels use it so that an overflow of fp16 storage (inf, then inf - inf) reaches the output as a non-finite value instead of
+// being clamped to a plausible-looking zero.  (The fp32 Winograd kernels keep v_max_f32 in their tuned epilogues: their contract is
+// finite inputs)
+__device__ __forceinline__ float relu_keep_nan(float v) { return v < 0.f ? 0.f : v; }
+#endif
+
 // One activation source of a convolution (fp32 or fp16 storage, decided by the launcher).  (offY, offX) is
 // the zero-pad placed above / left of the tensor when it is aligned to the output domain (UpSampleLayer's F.pad,
 // reference model.py:44-47).

@@ -24,6 +24,7 @@
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 namespace adn {
@@ -50,10 +51,21 @@ constexpr int C16_WPIECES = (C16_W_SLOTS / 64 + 7) / 8;    // weight copies per 
 #define C16_PPT 2                                 // copies issued per tap (from tap 0 on)
 #endif
 constexpr int C16_B_SLOTS = 64;                   // one wave copy: the 64 biases of the cout tile in the first 16 slots
-template <bool WRES> struct C16Lds {
+// FIRST (down1's second conv, model.py:11-16 via :56): the 64-channel input of the layer is never read -- the halo image of a chunk
+// is COMPUTED from the network input by the first convolution Conv2d(1 -> 64) + BN + ReLU on the same matrix cores (K = 32 =
+// 9 taps of the fp16 leading part + 9 taps of the fp16 remainder of each input value, so the input enters with 22 mantissa bits)
+// instead of being copied: conv_first_kernel's launch, its 4.3 GB of writes and this layer's 4.3 GB of reads at batch 256 go away.
+// The (36 x 20)-pixel input window of an item lives in LDS as two fp16 planes (leading part / remainder), double buffered.
+constexpr int C16_WIN_ROWS = C16_TH + 4, C16_WIN_COLS = C16_TW + 4, C16_WIN_N = C16_WIN_ROWS * C16_WIN_COLS;   // 36 x 20 = 720
+constexpr int C16_WIN_PLANE = 1536;               // bytes reserved per fp16 plane (720 halfs = 1440)
+constexpr int C16_WIN_BYTES = 2 * C16_WIN_PLANE;  // per window buffer
+constexpr int C16_HALO_PX = C16_PH * C16_PW;      // 612 halo pixels = 39 blocks of 16
+constexpr int C16_HALO_MB = (C16_HALO_PX + 15) / 16;
+template <bool WRES, bool FIRST = false> struct C16Lds {
     static constexpr int IMG_SLOTS = WRES ? C16_HALO_SLOTS : C16_HALO_SLOTS + C16_W_SLOTS + C16_B_SLOTS;
     static constexpr int RES_SLOTS = WRES ? 2 * C16_W_SLOTS + C16_B_SLOTS : 0;   // resident: weights of two chunks (Cin = 64) + biases
-    static constexpr size_t BYTES = (size_t)(RES_SLOTS + 2 * IMG_SLOTS) * 16;
+    static constexpr size_t BYTES = (size_t)(RES_SLOTS + 2 * IMG_SLOTS) * 16 + (FIRST ? 2 * C16_WIN_BYTES : 0);
+    static_assert(BYTES <= 160 * 1024, "LDS budget");
 };
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
@@ -92,10 +104,13 @@ __device__ __forceinline__ C16Item c16_decode(const ConvArgs &p, int id)
 }
 
 // EPI: CONV3X3_RELU / CONV3X3_RELU_POOL / CONV3X3_RELU_DOT (adn_internal.h).  WRES: weights resident in LDS (nchunk <= 2, nct == 1).
-template <int EPI, bool WRES>
+// FIRST: see C16Lds (needs WRES; p.s0.ptr = the network input (N,1,H,W) fp32, p.firstw [9][64] / p.firstb [64] fp32).
+template <int EPI, bool WRES, bool FIRST = false>
 __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
 {
-    using L = C16Lds<WRES>;
+    static_assert(!FIRST || WRES, "the fused first layer feeds a 64 -> 64 layer");
+    using L = C16Lds<WRES, FIRST>;
+    constexpr int WIN_OFF = (L::RES_SLOTS + 2 * L::IMG_SLOTS) * 16;
     constexpr int IMG_B = L::IMG_SLOTS * 16;                   // bytes per image
     constexpr int RES_B = L::RES_SLOTS * 16;
     constexpr int BIAS_OFF = (WRES ? 2 * C16_W_SLOTS : C16_HALO_SLOTS + C16_W_SLOTS) * 16;      // bias slots: resident region / image
@@ -145,13 +160,97 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
         hblk_bytes = (unsigned)(s.H * s.W) * 32u;
         hbase = static_cast<const char *>(s.ptr) + (size_t)it.n * himg_bytes;
     };
-    plan(p.s0, fi);
+    if constexpr (!FIRST) plan(p.s0, fi);
     const __amdgpu_buffer_rsrc_t wrs = dma_rsrc(p.wpk, (unsigned)((size_t)p.nct * nchunk * C16_W_SLOTS * 16));
     const __amdgpu_buffer_rsrc_t brs = dma_rsrc(p.bias, (unsigned)p.Cout * 4u);
+    // ---- FIRST: operands of the first convolution and the input window ----
+    int f_k = 0;                                    // ordinal of the fetch item among this workgroup's items (window buffer = f_k & 1)
+    f16x8 w1f[4];                                   // W fragment of cout block jj: lane (cout % 16, k group g): g even = taps 0-7, g odd = tap 8
+    f32x4 b1[4];                                    // folded-BN bias of couts 16 jj + 4 g .. + 3 (the accumulator's starting value)
+    float wl[2] = {0.f, 0.f};                       // window values of the NEXT item in flight (elements tid, tid + 512)
+    if constexpr (FIRST) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int t = (g & 1) ? 8 : e;
+                const float wv = p.firstw[t * 64 + 16 * jj + l16];
+                w1f[jj][e] = ((g & 1) && e > 0) ? (_Float16)0.f : (_Float16)wv;
+            }
+            b1[jj] = *reinterpret_cast<const f32x4 *>(p.firstb + 16 * jj + 4 * g);
+        }
+    }
+    auto win_issue = [&](const C16Item &it) {       // loads of item `it`'s window into registers (out of range = zero padding)
+        const __amdgpu_buffer_rsrc_t xrs = dma_rsrc(static_cast<const float *>(p.s0.ptr) + (size_t)it.n * p.H * p.W, (unsigned)(p.H * p.W) * 4u);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int e = tid + k * C16_NT;
+            const int wr = e / C16_WIN_COLS, wc = e - wr * C16_WIN_COLS;
+            const int gy = it.ty * C16_TH - 2 + wr, gx = it.tx * C16_TW - 2 + wc;
+            const unsigned off = (e < C16_WIN_N && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) ? (unsigned)((gy * p.W + gx) * 4) : ADN_DMA_OOB;
+            wl[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, off, 0, 0));
+        }
+    };
+    auto win_write = [&](int wb) {                  // split into the fp16 leading part and remainder, into window buffer wb
+        _Float16 *hi = reinterpret_cast<_Float16 *>(smem16 + WIN_OFF + wb * C16_WIN_BYTES);
+        _Float16 *lo = reinterpret_cast<_Float16 *>(smem16 + WIN_OFF + wb * C16_WIN_BYTES + C16_WIN_PLANE);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int e = tid + k * C16_NT;
+            if (e < C16_WIN_N) {
+                const _Float16 h = (_Float16)wl[k];
+                hi[e] = h;
+                lo[e] = (_Float16)(wl[k] - (float)h);
+            }
+        }
+    };
+    // halo block m (16 pixels) of chunk FC (0 / 1) of the fetch item, into image `buf`: gather the 3x3 windows of its pixels from the
+    // fp16 planes, two MFMAs (16 channels each), bias + ReLU, zero outside the image (the layer's own zero padding), 8-byte LDS writes
+    // block m = 8 q + wave of piece q: its lanes' halo pixel is fixed for the whole kernel
+    int fb_rowpx[FIRST ? 5 : 1];                    // row | px << 8 | valid << 16
+    if constexpr (FIRST) {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            int hp = 16 * (8 * q + wave) + l16;
+            const int valid = hp < C16_HALO_PX ? 1 : 0;
+            hp = valid ? hp : C16_HALO_PX - 1;
+            const int row = hp / C16_PW;
+            fb_rowpx[q] = row | ((hp - row * C16_PW) << 8) | (valid << 16);
+        }
+    }
+    auto first_block = [&](int q, int buf, auto fc_tag) {
+        constexpr int FC = decltype(fc_tag)::value;
+        const int row = fb_rowpx[FIRST ? q : 0] & 0xff, px = (fb_rowpx[FIRST ? q : 0] >> 8) & 0xff;
+        const bool valid = (fb_rowpx[FIRST ? q : 0] >> 16) & 1;
+        const _Float16 *wp = reinterpret_cast<const _Float16 *>(smem16 + WIN_OFF + (f_k & 1) * C16_WIN_BYTES + (g >= 2 ? C16_WIN_PLANE : 0)) +
+                             row * C16_WIN_COLS + px;
+        _Float16 t[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) t[k] = wp[(k / 3) * C16_WIN_COLS + (k % 3)];
+        const _Float16 z = (_Float16)0.f;
+        const bool odd = g & 1;
+        const f16x8 xf = {odd ? t[8] : t[0], odd ? z : t[1], odd ? z : t[2], odd ? z : t[3], odd ? z : t[4], odd ? z : t[5], odd ? z : t[6], odd ? z : t[7]};
+        const int gy = fi.ty * C16_TH - 1 + row, gx = fi.tx * C16_TW - 1 + px;
+        const bool inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        char *dst = img_base + buf * IMG_B + row * C16_ROWB + px * 32 + g * 8;
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+            const f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1f[2 * FC + jb], xf, b1[2 * FC + jb], 0, 0, 0);
+            f16x4 hv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hv[r] = inside ? (_Float16)relu_keep_nan(a[r]) : z;
+            if (valid) *reinterpret_cast<f16x4 *>(dst + jb * (C16_BLK_SLOTS * 16)) = hv;
+        }
+    };
     // piece q (0 .. NPIECE-1) of the fetch step into image `buf`
     auto fetch_piece = [&](int q, int buf) {
         char *img = img_base + buf * IMG_B;
-        if (q < C16_HPIECES) {
+        if constexpr (FIRST) {
+            if (8 * q + wave < C16_HALO_MB) {                            // 39 blocks over 8 waves x 5 pieces
+                if (f_chunk == 0) first_block(q, buf, std::integral_constant<int, 0>{});
+                else first_block(q, buf, std::integral_constant<int, 1>{});
+            }
+        } else if (q < C16_HPIECES) {
             const int pi = 8 * q + wave;                             // wave-uniform piece index (0 .. 39)
             const int blk = pi >= 20 ? 1 : 0;
             const int cl = f_chunk < p.nchunk0 ? f_chunk : f_chunk - p.nchunk0;      // chunk inside the current source
@@ -179,15 +278,17 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
         if (++f_chunk == nchunk) {
             f_chunk = 0;
             f_item += gsz;
+            ++f_k;
             if (f_item < nitems) {
                 fi = c16_decode(p, f_item);
-                plan(p.s0, fi);
+                if constexpr (!FIRST) plan(p.s0, fi);
             }
         } else if (f_chunk == p.nchunk0) {
-            plan(p.s1, fi);                         // virtual concat: the second source (with its pad offset)
+            if constexpr (!FIRST) plan(p.s1, fi);   // virtual concat: the second source (with its pad offset)
         }
     };
-    constexpr int NPIECE = C16_HPIECES + (WRES ? 0 : C16_WPIECES);
+    constexpr int PPT = FIRST ? 1 : C16_PPT;       // pieces per tap (the computed halo blocks are heavier than a copy: one per tap)
+    constexpr int NPIECE = FIRST ? (C16_HALO_MB + 7) / 8 : C16_HPIECES + (WRES ? 0 : C16_WPIECES);
 
     // ---- prologue: resident weights + biases, first step's copies ----
     if constexpr (WRES) {
@@ -198,12 +299,18 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
         }
         if (wave == 0) dma16_buf(brs, lane < 16 ? lane * 16 : ADN_DMA_OOB, 0u, reinterpret_cast<float *>(smem16 + BIAS_OFF));
     }
+    if constexpr (FIRST) {                          // window of the first item, then its first chunk's halo
+        win_issue(fi);
+        win_write(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
 #pragma unroll
     for (int q = 0; q < NPIECE; ++q) fetch_piece(q, 0);
     fetch_advance();
 
     // ---- compute side ----
-    int c_item = first, c_chunk = 0;
+    int c_item = first, c_chunk = 0, c_k = 0;
     C16Item ci = c16_decode(p, c_item);
     f32x4 acc[4][4];                                // [pixel row block i][cout block j]: lane = (pixel l16, couts 4g .. 4g+3)
 
@@ -227,6 +334,14 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
         const bool more = s + 1 < nsteps;
         const char *img = img_base + buf * IMG_B;
         const char *wimg = WRES ? smem16 + c_chunk * (C16_W_SLOTS * 16) : img + C16_HALO_SLOTS * 16;
+        bool win_pending = false;
+        if constexpr (FIRST) {
+            // first step of an item: the NEXT item's window starts its trip (its first halo is computed in the next step)
+            if (c_chunk == 0 && c_item + gsz < nitems) {
+                win_issue(c16_decode(p, c_item + gsz));
+                win_pending = true;
+            }
+        }
         if (c_chunk == 0) {
             // folded-BN bias rides in the accumulators (the copies staged it in LDS): no bias load or add in the epilogue
             const char *bl = (WRES ? smem16 : img) + BIAS_OFF + g * 16;
@@ -256,7 +371,7 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
             // the step to land before the wait at its end
             if (more) {
 #pragma unroll
-                for (int q = tap * C16_PPT; q < (tap + 1) * C16_PPT; ++q)
+                for (int q = tap * PPT; q < (tap + 1) * PPT; ++q)
                     if (q < NPIECE) fetch_piece(q, buf ^ 1);
             }
 #ifdef ADN_EXPERIMENTS
@@ -288,7 +403,7 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) part[i] += w[r] * fmaxf(acc[i][j][r], 0.f);
+                        for (int r = 0; r < 4; ++r) part[i] += w[r] * relu_keep_nan(acc[i][j][r]);
                 }
                 const __amdgpu_buffer_rsrc_t yrs = dma_rsrc(p.dot_out + (size_t)ci.n * p.H * p.W, (unsigned)(p.H * p.W) * 4u);
 #pragma unroll
@@ -318,7 +433,7 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[i][r] = fmaxf(acc[i][j][r], 0.f);
+                        for (int r = 0; r < 4; ++r) v[i][r] = relu_keep_nan(acc[i][j][r]);
                         const f16x4 hv = {(_Float16)v[i][0], (_Float16)v[i][1], (_Float16)v[i][2], (_Float16)v[i][3]};
                         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hv), ors, ooff[i], cb, 0);
                     }
@@ -342,6 +457,7 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
                 }
             }
             c_item += gsz;
+            ++c_k;
             if (c_item < nitems) ci = c16_decode(p, c_item);
             // this wave's copies of the next step have landed; its NST stores (younger than every copy) may still be in flight
             constexpr int NST = EPI == CONV3X3_RELU_DOT ? 4 : EPI == CONV3X3_RELU_POOL ? 24 : 16;
@@ -354,6 +470,9 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
             else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if constexpr (FIRST) {
+            if (win_pending) win_write((c_k + 1) & 1);     // (the loads are older than this step's stores: the compiler's wait leaves those in flight)
         }
 #ifdef ADN_EXPERIMENTS
         unsigned long long tl_w = 0;
@@ -377,10 +496,10 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
 #endif
 }
 
-template <int EPI, bool WRES>
+template <int EPI, bool WRES, bool FIRST = false>
 hipError_t launch_c16(const ConvArgs &a, hipStream_t st)
 {
-    using L = C16Lds<WRES>;
+    using L = C16Lds<WRES, FIRST>;
     ConvArgs a2 = a;
     a2.tilesY = (a.H + C16_TH - 1) / C16_TH;
     a2.tilesX = (a.W + C16_TW - 1) / C16_TW;
@@ -408,7 +527,7 @@ hipError_t launch_c16(const ConvArgs &a, hipStream_t st)
         cus.store(c, std::memory_order_relaxed);
     }
     long grid = nitems < c ? ((nitems + 7) & ~7L) : c;   // one resident workgroup per CU walks the items
-    auto kern = conv16_f16<EPI, WRES>;
+    auto kern = conv16_f16<EPI, WRES, FIRST>;
     static std::atomic<unsigned long long> attr_mask{0};
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(attr_mask.load(std::memory_order_acquire) & bit)) {
@@ -453,7 +572,8 @@ hipError_t launch_c16(const ConvArgs &a, hipStream_t st)
 bool conv16_applicable(ConvKind kind, const ConvArgs &a)
 {
     if (kind != CONV3X3_RELU && kind != CONV3X3_RELU_POOL && kind != CONV3X3_RELU_DOT) return false;
-    if ((a.s0.C & 31) || (a.s1.C & 31) || (a.Cout & 63) || a.firstw) return false;
+    if (a.firstw) return kind == CONV3X3_RELU_POOL && a.firstb && a.s0.C == 1 && a.s1.C == 0 && a.Cout == 64;   // fused first layer
+    if ((a.s0.C & 31) || (a.s1.C & 31) || (a.Cout & 63)) return false;
     if (kind == CONV3X3_RELU_DOT && (a.Cout != 64 || !a.dotw || !a.dot_out)) return false;
     return true;
 }
@@ -462,6 +582,7 @@ hipError_t launch_conv16(ConvKind kind, const ConvArgs &a, bool resident, hipStr
 {
     if (!conv16_applicable(kind, a)) return hipErrorInvalidValue;
     if (resident && (a.nchunk > 2 || a.Cout != 64)) return hipErrorInvalidValue;
+    if (a.firstw) return (resident && a.nchunk == 2) ? launch_c16<CONV3X3_RELU_POOL, true, true>(a, st) : hipErrorInvalidValue;
     if (resident) {
         if (kind == CONV3X3_RELU_DOT) return launch_c16<CONV3X3_RELU_DOT, true>(a, st);
         if (kind == CONV3X3_RELU_POOL) return launch_c16<CONV3X3_RELU_POOL, true>(a, st);

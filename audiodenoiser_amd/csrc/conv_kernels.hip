@@ -111,7 +111,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &p, f32x16 (&acc)[T
             } else {
                 float v[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc[i][j][r] + bv, 0.f);
+                for (int r = 0; r < 16; ++r) v[r] = relu_keep_nan(acc[i][j][r] + bv);
                 T *ob = outp + (size_t)n * p.H * p.W * p.Cout + act_off<T>(p.Cout, (long)p.H * p.W, 0, col);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -350,7 +350,7 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs &p, f32x16 (
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 v[r] = acc[i][j][r] + bv;
-                if (EPI != CONVT2X2) v[r] = fmaxf(v[r], 0.f);
+                if (EPI != CONVT2X2) v[r] = relu_keep_nan(v[r]);
             }
             if constexpr (sizeof(T) == 4) {
 #pragma unroll
