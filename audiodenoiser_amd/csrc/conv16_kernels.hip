@@ -666,7 +666,6 @@ hipError_t launch_conv16(ConvKind kind, const ConvArgs &a, bool resident, hipStr
 #else
     constexpr bool rs = false;
 #endif
-    if (resident) {
 #ifdef ADN_EXPERIMENTS
     if (rs) {
         if (resident) {
