@@ -293,7 +293,11 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
         } else if (q < C16_HPIECES) {
             // (descriptor words through readfirstlane, halo_rsrc: they are wave-uniform, but hipcc keeps loop-carried scalars in VGPRs
             // when it runs short of SGPRs, and a descriptor in VGPRs makes every copy a waterfall loop)
+#ifdef C16_HALO_NT
+            if constexpr (!RS) dma16_buf_nt(halo_rsrc(), hcur[q], halo_soff(q), reinterpret_cast<float *>(img + (8 * q + wave) * 1024));
+#else
             if constexpr (!RS) dma16_buf(halo_rsrc(), hcur[q], halo_soff(q), reinterpret_cast<float *>(img + (8 * q + wave) * 1024));
+#endif
         } else if (!WRES) {
             const int pi = 8 * (q - C16_HPIECES) + wave;             // 0 .. 39: the slab has 36 pieces, piece 36 carries the biases
             if (pi < C16_W_SLOTS / 64) {

@@ -362,7 +362,8 @@ def bench_f16(sd_np, dev, batch=256, steps=10, warmup=2):
            "steps": steps, "warmup": warmup, "dtype": "f16", "ms_per_step": round(el / steps * 1e3, 3),
            "frames_per_s": round(batch * T_FRAMES * steps / el, 1),
            "roofline": conv_roofline(ms_mean, batch, "direct_f16", PEAK_MFMA_F16_TFLOPS,
-                                     "conv_dma<_Float16, 32, 64, ...> (LDS-DMA staged direct implicit GEMM, v_mfma_f32_32x32x16_f16)", "conv_mfma_f16"),
+                                     "conv_dma<_Float16, 32, 64, ...> (LDS-DMA staged direct implicit GEMM, v_mfma_f32_32x32x16_f16; 14 layers) + conv16_f16 "
+                                     "(v_mfma_f32_16x16x32_f16, persistent, LDS-resident weights / fused first layer; the 3 layers fed by 64 channels)", "conv_mfma_f16"),
            "forward": forward_summary(ms_mean, batch, "direct_f16", PEAK_MFMA_F16_TFLOPS)}
     net._release()
     del net, x, target
@@ -461,7 +462,7 @@ def kernel_names(f16: bool):
     algo = "direct_f16" if f16 else ("direct" if direct else "winograd")
     peak = PEAK_MFMA_F16_TFLOPS if f16 else PEAK_MFMA_F32_TFLOPS
     wmode = wino_tile_mode()
-    kname = ("conv_dma<_Float16, 32, 64, ...> (LDS-DMA staged direct implicit GEMM, fp16 MFMA)" if f16 else
+    kname = ("conv_dma<_Float16, 32, 64, ...> + conv16_f16 (LDS-DMA staged direct implicit GEMM, fp16 MFMA)" if f16 else
              "conv_mfma<float> (direct implicit GEMM, fp32 MFMA)" if direct else
              "wino_conv_dma_f32 (Winograd F(2x2,3x3), fp32 MFMA v_mfma_f32_16x16x4_f32)" if wmode == "2" else
              "wino4_conv_f32 (Winograd F(4x4,3x3), fp32 MFMA v_mfma_f32_16x16x4_f32)")

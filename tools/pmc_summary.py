@@ -28,7 +28,9 @@ FAMILIES = {
     "wino4_conv_f32": lambda n: n.startswith("wino4_conv_f32"),
     "wino_conv_dma_f32": lambda n: n.startswith("wino_conv_dma_f32"),
     "conv_mfma_f32": lambda n: n.startswith("conv_mfma<float") and ", 9, " in n,
-    "conv_mfma_f16": lambda n: n.startswith(("conv_mfma<_Float16", "conv_dma<_Float16")) and ", 9, " in n,
+    # fp16 3x3 layers: conv_dma<_Float16, 32, 64, ...> (32x32x16 MFMA) and conv16_f16<...> (16x16x32 MFMA, round 4)
+    "conv_mfma_f16": lambda n: (n.startswith(("conv_mfma<_Float16", "conv_dma<_Float16")) and ", 9, " in n) or n.startswith("conv16_f16"),
+    "conv16_f16": lambda n: n.startswith("conv16_f16"),
     # transposed convolutions: <T, TH = 8, BN = 128, WM = 2, WN = 2, TAPS = 1, ...> (split-bf16 form: conv_dma<float, 8, 128, 2, 2, 1, 2, 2, 3, 1>)
     "convt_f32": lambda n: n.startswith(("conv_mfma<float", "conv_dma<float")) and ", 8, 128, 2, 2, 1, " in n,
     "convt_f16": lambda n: n.startswith(("conv_mfma<_Float16", "conv_dma<_Float16")) and ", 8, 128, 2, 2, 1, " in n,
@@ -77,7 +79,7 @@ def short(name: str) -> str:
 
 
 def ours(n: str) -> bool:
-    return n.startswith(("conv_", "stft", "per_clip", "nhwc", "quantize", "wino", "loss_", "gl_", "istft"))
+    return n.startswith(("conv_", "conv16", "stft", "per_clip", "nhwc", "quantize", "wino", "loss_", "gl_", "istft", "dot_finish"))
 
 
 def read_counter(d, counter):

@@ -34,3 +34,21 @@ g = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "co
 with torch.no_grad():
     y = net(torch.from_numpy(g["x_f16"].astype(np.float32)[None, None]).cuda()).cpu().numpy()[0, 0]
 print(f"{algo:9s} config0 real audio 513x256: max|y-ref|/max|ref| = {np.abs(y - g['y']).max() / np.abs(g['y']).max():.2e}")
+
+# goldens under trained-like BatchNorm statistics / heavy-tailed weights, real-audio input at scale 1 and 100 (per clip)
+from audiodenoiser_amd.weights import make_state_dict_variant  # noqa: E402
+gd = os.path.join(os.path.dirname(__file__), "..", "tests", "golden")
+x16 = np.load(os.path.join(gd, "config0_real_audio.npz"))["x_f16"]
+for kind in ("trained", "heavy"):
+    sdv = make_state_dict_variant(kind, 1234)
+    nv = UNet()
+    nv.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sdv.items()})
+    nv = nv.cuda().eval()
+    for (f, t) in ((33, 47), (257, 188), (513, 256)):
+        g = np.load(os.path.join(gd, f"unet_{kind}_{f}x{t}.npz"))
+        x = x16[:f, :t].astype(np.float32)
+        xb = torch.from_numpy(np.stack([x, x * np.float32(100.0)])[:, None]).cuda()
+        with torch.no_grad():
+            y = nv(xb).cpu().numpy()
+        e = [np.abs(y[c] - g["y"][c]).max() / np.abs(g["y"][c]).max() for c in range(2)]
+        print(f"{algo:9s} weights '{kind}' 2x1x{f}x{t}: max|y-ref|/max|ref| = {e[0]:.2e} (x1)  {e[1]:.2e} (x100)")

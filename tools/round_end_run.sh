@@ -17,3 +17,7 @@ import json
 d=json.load(open('gpurun_out/r04_bench.json')); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['traffic'], d['stft']['ms_per_launch'], d['f16']['frames_per_s'], d['cpu_baseline']['value'])
 d=json.load(open('gpurun_out/r04_bench_b256.json')); print(d['value'], d['ms_per_step'])"
 cat gpurun_out/r04_parity.txt
+# matrix-pipe busy / clock / wave-state counters of the dominant kernels of the FINAL build (fp32: wino4_conv_f32; fp16: conv_dma + conv16)
+bash tools/sq_counters.sh wino4 > gpurun_out/r04_wino4_sq_counters.txt 2>&1 || true
+BENCH_ARGS="--dtype f16 --batch-per-gpu 256" bash tools/sq_counters.sh conv > gpurun_out/r04_f16_sq_counters.txt 2>&1 || true
+tail -12 gpurun_out/r04_wino4_sq_counters.txt
