@@ -79,6 +79,7 @@ struct ConvArgs {
     const void *wpk;       // packed weights, see pack_* in adn_api.hip
     const void *wpk4;      // fp32 3x3 layers: the same weights packed for the F(4x4,3x3) kernel (pack_wino4_3x3), or nullptr
     const float *bias;     // per GEMM column (BatchNorm folded), always fp32
+    const float *bias16;   // fp16 path, conv16_f16 only: half the bias (pack_conv16 in adn_api.hip), or nullptr
     void *out;             // output in the blocked layout (above)
     void *pool;            // optional 2x2 max-pooled output, same layout (CONV3X3_RELU_POOL)
     int N, H, W;           // tile domain: output H,W for 3x3; INPUT h,w for the transposed convolution

@@ -47,6 +47,9 @@ constexpr int C16_W_SLOTS = 9 * 4 * 64;           // weight slab of a chunk: [ta
 constexpr int C16_HPIECES = C16_HALO_SLOTS / 64 / 8;       // halo copies per wave and chunk (5)
 constexpr int C16_WPIECES = (C16_W_SLOTS / 64 + 7) / 8;    // weight copies per wave and chunk (5, the last half used)
 
+#ifndef C16_PRIO                                  // 0 = none, 1 = static s_setprio 1 for waves 4-7, 2 = alternating per tap
+#define C16_PRIO 0
+#endif
 #ifndef C16_PPT
 #define C16_PPT 2                                 // copies issued per tap (from tap 0 on)
 #endif
@@ -369,6 +372,11 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
     // the chunk = half (g & 1) of block (g >> 1) at pixel (4 wave + i + dy, l16 + dx)
     const int x_lane = (g >> 1) * (C16_BLK_SLOTS * 16) + (g & 1) * 16 + l16 * 32 + wave * 4 * C16_ROWB;
     const int w_lane = lane * 16;
+    f32x4 dotw_r[4];                                // DOT: the 1x1 weights of this lane's 16 channels (16 j + 4 g + r)
+    if constexpr (EPI == CONV3X3_RELU_DOT) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dotw_r[j] = *reinterpret_cast<const f32x4 *>(p.dotw + 16 * j + 4 * g);
+    }
 
     if constexpr (RS) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");      // the five loads of step 1's halo stay in flight
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -405,45 +413,69 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
                 for (int i = 0; i < 4; ++i) acc[i][j] = b;
             }
         }
-        // fragments of a tap are read one tap ahead of its MFMAs
-        f16x8 xf[2][4], wf[2][4];
-        auto load_tap = [&](int tap, int slot) {
-            const int dy = tap / 3, dx = tap % 3;
+        // Fragment reads.  The X fragment of (row block i, tap (dy, dx)) is halo row 4 wave + i + dy at column offset dx: for one
+        // dx the six rows 4 wave .. 4 wave + 5 serve all twelve (i, dy) pairs, so the taps are walked dx-major -- 6 X + 12 W
+        // fragment reads per 48 MFMAs (0.375 per MFMA) instead of 8 per 16.  X rows are read one dx ahead, W fragments one tap ahead.
+        f16x8 xr[2][6], wf[2][4];
+        auto load_x = [&](int dx, int slot) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                wf[slot][j] = *reinterpret_cast<const f16x8 *>(wimg + w_lane + (tap * 4 + j) * 1024);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                xf[slot][i] = *reinterpret_cast<const f16x8 *>(img + x_lane + (i + dy) * C16_ROWB + dx * 32);
+            for (int r = 0; r < 6; ++r) xr[slot][r] = *reinterpret_cast<const f16x8 *>(img + x_lane + r * C16_ROWB + dx * 32);
         };
-        load_tap(0, 0);
+        auto load_w = [&](int tp, int slot) {           // tp = position in the dx-major order: tap = dy * 3 + dx
+            const int tap = (tp % 3) * 3 + tp / 3;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            if (tap < 8) load_tap(tap + 1, (tap + 1) & 1);
-            // the next step's copies go out between the first taps' MFMA groups (C16_PPT per tap): the last one has the rest of
+            for (int j = 0; j < 4; ++j) wf[slot][j] = *reinterpret_cast<const f16x8 *>(wimg + w_lane + (tap * 4 + j) * 1024);
+        };
+#ifdef ADN_EXPERIMENTS
+        // timing experiments (ADN_C16_ABLATE, results wrong by design): 1 = no fragment reads / MFMAs, 2 = no copies after the
+        // prologue, 4 = no epilogue stores
+        const int abl = p.ablate;
+#else
+        constexpr int abl = 0;
+#endif
+        if (!(abl & 1)) {
+            load_x(0, 0);
+            load_w(0, 0);
+        }
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+            const int dx = tp / 3, dy = tp % 3;
+            if (!(abl & 1)) {
+                if (tp < 8) load_w(tp + 1, (tp + 1) & 1);
+                if (dy == 1 && dx < 2) load_x(dx + 1, (dx + 1) & 1);
+            }
+            // the next step's copies go out between the first taps' MFMA groups (PPT per tap): the last one has the rest of
             // the step to land before the wait at its end
             if constexpr (RS) {
-                // weights of the next step first (taps 0-2), then the halo of the step after it into registers: in issue order
-                // the loads are the youngest, so the wait at the end of the step can leave exactly them in flight
+                // weights of the next step first, then the halo of the step after it into registers: in issue order the loads
+                // are the youngest, so the wait at the end of the step can leave exactly them in flight
                 if (more) {
 #pragma unroll
-                    for (int q = C16_HPIECES + tap * PPT; q < C16_HPIECES + (tap + 1) * PPT; ++q)
+                    for (int q = C16_HPIECES + tp * PPT; q < C16_HPIECES + (tp + 1) * PPT; ++q)
                         if (q < NPIECE) fetch_piece(q, buf ^ 1);
                 }
-                if (tap == (WRES ? 0 : 3)) halo_load(std::integral_constant<int, PAR>{});
-            } else if (more) {
+                if (tp == (WRES ? 0 : 3)) halo_load(std::integral_constant<int, PAR>{});
+            } else if (more && !(abl & 2)) {
 #pragma unroll
-                for (int q = tap * PPT; q < (tap + 1) * PPT; ++q)
+                for (int q = tp * PPT; q < (tp + 1) * PPT; ++q)
                     if (q < NPIECE) fetch_piece(q, buf ^ 1);
             }
 #ifdef ADN_EXPERIMENTS
-            if (tap == 8 && tl_on) tl_c = __builtin_amdgcn_s_memtime();
+            if (tp == 8 && tl_on) tl_c = __builtin_amdgcn_s_memtime();
 #endif
+#if C16_PRIO == 2
+            // the two waves of a SIMD (w, w + 4) take turns at the higher priority, tap by tap: the arbitration otherwise favours
+            // the older wave all step long and the younger one finishes its MFMAs alone, at a single wave's issue rate
+            if (((tp + (wave >> 2)) & 1)) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+#endif
+            if (!(abl & 1)) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tap & 1][j], xf[tap & 1][i], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tp & 1][j], xr[dx & 1][i + dy], acc[i][j], 0, 0, 0);
+            }
         }
         if constexpr (RS) {
             fetch_advance();                           // (the halo state runs two steps ahead, past the last step too: loads of nothing)
@@ -460,26 +492,31 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
             c_chunk = 0;
             const int gx = ci.tx * C16_TW + l16;
             const int gyb = ci.ty * C16_TH + wave * 4;
+            // ReLU in ONE vector operation that keeps NaN and +inf: the host packs HALF the weights and biases (pack_conv16: exact
+            // in binary floating point), so the accumulators hold y / 2 and y/2 + |y/2| = max(y, 0); v_max_f32 would turn a NaN
+            // into 0 (IEEE maxNum) and an overflow of fp16 storage upstream (inf, then inf - inf) into plausible-looking values.
+            auto relu2 = [](float h) { return h + __builtin_fabsf(h); };
+            auto relu_pk = [&](float a, float b) {
+                const f16x2 h = {(_Float16)relu2(a), (_Float16)relu2(b)};
+                return __builtin_bit_cast(unsigned, h);
+            };
             if constexpr (EPI == CONV3X3_RELU_DOT) {
-                // fused last layer (model.py:91,93): y[px] = bias1x1 + sum over the 64 channels of w1x1[c] * ReLU(conv[c][px]);
+                // fused last layer (model.py:91,93): y[px] = bias1x1 + sum over the 64 channels of w1x1[c] * ReLU(conv[c][px]) in fp32;
                 // a lane adds its 16 channels, the four k groups of a pixel meet by two exchanges (fixed order)
-                const float *dw = p.dotw + 4 * g;
                 float part[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f32x4 w = *reinterpret_cast<const f32x4 *>(dw + 16 * j);
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) part[i] += w[r] * relu_keep_nan(acc[i][j][r]);
-                }
+                        for (int r = 0; r < 4; ++r) part[i] = __builtin_fmaf(dotw_r[j][r], relu2(acc[i][j][r]), part[i]);
                 const __amdgpu_buffer_rsrc_t yrs = dma_rsrc(p.dot_out + (size_t)ci.n * p.H * p.W, (unsigned)(p.H * p.W) * 4u);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     float v = part[i];
                     v += __shfl_xor(v, 16, 64);
                     v += __shfl_xor(v, 32, 64);
-                    const unsigned off = (g == 0 && gyb + i < p.H && gx < p.W) ? (unsigned)(((gyb + i) * p.W + gx) * 4) : ADN_DMA_OOB;
+                    const unsigned off = (g == 0 && gyb + i < p.H && gx < p.W && !(abl & 4)) ? (unsigned)(((gyb + i) * p.W + gx) * 4) : ADN_DMA_OOB;
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v + p.dot_bias), yrs, off, 0, 0);
                 }
             } else {
@@ -493,33 +530,36 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
                 unsigned ooff[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    ooff[i] = (gyb + i < p.H && gx < p.W) ? (unsigned)(((gyb + i) * p.W + gx) * 32 + g * 8) : ADN_DMA_OOB;
+                    ooff[i] = (gyb + i < p.H && gx < p.W && !(abl & 4)) ? (unsigned)(((gyb + i) * p.W + gx) * 32 + g * 8) : ADN_DMA_OOB;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const unsigned cb = (unsigned)__builtin_amdgcn_readfirstlane((ci.ct * 4 + j) * (int)HWb);
-                    f32x4 v[4];
+                    u32x2 hv[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[i][r] = relu_keep_nan(acc[i][j][r]);
-                        const f16x4 hv = {(_Float16)v[i][0], (_Float16)v[i][1], (_Float16)v[i][2], (_Float16)v[i][3]};
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hv), ors, ooff[i], cb, 0);
+                        hv[i] = u32x2{relu_pk(acc[i][j][0], acc[i][j][1]), relu_pk(acc[i][j][2], acc[i][j][3])};
+                        __builtin_amdgcn_raw_buffer_store_b64(hv[i], ors, ooff[i], cb, 0);
                     }
                     if constexpr (EPI == CONV3X3_RELU_POOL) {
-                        // MaxPool2d(2), floor mode: rows (2a, 2a+1) are this lane's row blocks, columns (2x, 2x+1) neighbouring lanes
+                        // MaxPool2d(2), floor mode, on the packed halfs (rounding is monotonic: the maximum of the rounded values is the
+                        // rounded maximum; the values are >= 0 or NaN -- a NaN is dropped HERE (v_pk_max_f16), it stays in the skip
+                        // tensor): rows (2a, 2a+1) are this lane's row blocks, columns (2x, 2x+1) neighbouring lanes
                         const unsigned cbp = (unsigned)__builtin_amdgcn_readfirstlane((ci.ct * 4 + j) * (int)HWpb);
 #pragma unroll
                         for (int a = 0; a < 2; ++a) {
-                            f32x4 m;
+                            u32x2 m;
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const float t = fmaxf(v[2 * a][r], v[2 * a + 1][r]);
-                                m[r] = fmaxf(t, __shfl_xor(t, 1, 64));
+                            for (int d = 0; d < 2; ++d) {
+                                // (vector elements through named temporaries: __builtin_bit_cast of `vec[d]` itself reads element 0 whatever d is)
+                                const unsigned r0 = hv[2 * a][d], r1 = hv[2 * a + 1][d];
+                                const f16x2 t = __builtin_elementwise_max(__builtin_bit_cast(f16x2, r0), __builtin_bit_cast(f16x2, r1));
+                                const unsigned tu = __builtin_bit_cast(unsigned, t);
+                                const unsigned ou = (unsigned)__shfl_xor((int)tu, 1, 64);
+                                m[d] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(t, __builtin_bit_cast(f16x2, ou)));
                             }
                             const int py = (gyb >> 1) + a, px = gx >> 1;
-                            const unsigned poff = (!(l16 & 1) && py < Hp && px < Wp) ? (unsigned)((py * Wp + px) * 32 + g * 8) : ADN_DMA_OOB;
-                            const f16x4 hm = {(_Float16)m[0], (_Float16)m[1], (_Float16)m[2], (_Float16)m[3]};
-                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hm), prs, poff, cbp, 0);
+                            const unsigned poff = (!(l16 & 1) && py < Hp && px < Wp && !(abl & 4)) ? (unsigned)((py * Wp + px) * 32 + g * 8) : ADN_DMA_OOB;
+                            __builtin_amdgcn_raw_buffer_store_b64(m, prs, poff, cbp, 0);
                         }
                     }
                 }
@@ -597,6 +637,10 @@ hipError_t launch_c16(const ConvArgs &a, hipStream_t st)
     a2.fdTx = make_fastdiv((unsigned)a2.tilesX);
     a2.fdTy = make_fastdiv((unsigned)a2.tilesY);
     a2.nwg_total = (int)nitems;
+    a2.ablate = 0;
+#ifdef ADN_EXPERIMENTS
+    { const char *ab = std::getenv("ADN_C16_ABLATE"); a2.ablate = ab ? std::atoi(ab) : 0; }
+#endif
     static std::atomic<int> cus{0};                   // (one device model per process: gfx950 only, checked at handle creation)
     int c = cus.load(std::memory_order_relaxed);
     int dev = 0;
