@@ -92,8 +92,10 @@ struct adn_unet {
     size_t first_w = 0, first_b = 0;       // Conv2d(1->64): [9][64] + bias[64]
     Conv3x3Layer c3[17];                   // the 17 MFMA 3x3 convolutions in execution order
     ConvTLayer ct[4];
-    size_t out_w = 0;
-    float out_b = 0.f;
+    size_t out_w = 0;               // Conv2d(64 -> num_classes, 1x1): [class][64]
+    float out_b = 0.f;              // bias of class 0 (the fused 1x1 tails handle one class)
+    std::vector<float> out_bias;    // all classes
+    int in_ch = 1, n_classes = 1;   // UNet(in_channels, num_classes) (model.py:54); the reference's callers use (1, 1)
     // optional per-launch timing (adn_unet_set_timing)
     std::vector<hipEvent_t> events;
     int timing_max = 0, timing_count = 0;
@@ -508,6 +510,8 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
     // b128 accesses; x and y are accessed as single floats
     if (!aligned_to(workspace, 16)) return fail(ADN_ERR_INVALID, "adn_unet_forward: workspace must be 16-byte aligned");
     if (!aligned_to(x, 4) || !aligned_to(y, 4)) return fail(ADN_ERR_INVALID, "adn_unet_forward: x and y must be 4-byte aligned");
+    if ((long)h->in_ch * (T + 2) > 4096)
+        return fail(ADN_ERR_INVALID, "adn_unet_forward: in_channels * (T + 2) must be <= 4096 (the first layer stages its input window on chip)");
     DeviceGuard guard(h->device);
     if (guard.err != hipSuccess) return fail_hip(guard.err, "hipSetDevice");
 
@@ -532,7 +536,7 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
     // ---- down path (model.py:72-79) ----
     // Winograd path: the first convolution (Cin = 1) is fused into down1's second one -- its 64-channel result is computed
     // tile by tile inside that kernel and never written (timing slot 0 stays empty).
-    bool fused_first = h->use_wino;
+    bool fused_first = h->use_wino && h->in_ch == 1;     // (the fused forms compute Conv2d(1 -> 64); more input planes: own launch)
     if (fused_first) {
         // where the F(4x4,3x3) kernel takes down1's second conv the first layer runs as its own launch (the fused form is
         // time-neutral on F(2x2,3x3); unfused + F(4x4,3x3) is 1.1 ms faster at batch 64); split-K has no fused variant either
@@ -541,10 +545,10 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
         if (algo.f4 || algo.ksplit > 1) fused_first = false;
     }
     // fp16 path: the first layer is computed inside conv16_f16's halo stage of down1's second conv (conv16_kernels.hip, FIRST)
-    if (f16 && h->f16_conv != 0 && h->f16_fuse_first && h->c3[0].w16_off) fused_first = true;
+    if (f16 && h->f16_conv != 0 && h->f16_fuse_first && h->c3[0].w16_off && h->in_ch == 1) fused_first = true;
     ADN_MARK();
     if (!fused_first)
-        ADN_HIP(adn::launch_conv_first(x, h->dev + h->first_w, h->dev + h->first_b, tA, f16, N, p.H[0], p.W[0], st));
+        ADN_HIP(adn::launch_conv_first(x, h->dev + h->first_w, h->dev + h->first_b, tA, f16, N, p.H[0], p.W[0], h->in_ch, st));
     int li = 0;
     const void *cur = tA;
     for (int l = 0; l < 4; ++l) {
@@ -635,8 +639,9 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
         // on the Winograd path: the 64-channel tensor between them is never written (Y holds the two partial planes
         // instead).  Not when block outputs are exported (the up4 tap IS that tensor).
         // fp16 path: a workgroup of conv_dma holds all 64 channels, the dot is finished in its epilogue (writes y).
-        const bool fuse_f16 = l == 0 && f16 && !taps && b.nct == 1;
-        fused_out = l == 0 && h->use_wino && !taps && b.nct == 2;
+        // (the fused tails finish ONE class; UNet(..., num_classes > 1) runs the 1x1 convolution class by class below)
+        const bool fuse_f16 = l == 0 && f16 && !taps && b.nct == 1 && h->n_classes == 1;
+        fused_out = l == 0 && h->use_wino && !taps && b.nct == 2 && h->n_classes == 1;
         if (fused_out) {
             b.dotw = h->dev + h->out_w;
             b.dot_out = static_cast<float *>(Y);
@@ -664,7 +669,9 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
     } else if (fused_out)      // X = the buffer the fused layer wrote its partial planes to (the loop swapped X and Y)
         ADN_HIP(adn::launch_dot_finish(static_cast<const float *>(X), 2, h->out_b, y, (long)N * F * T, st));
     else
-        ADN_HIP(adn::launch_conv_out(X, f16, h->dev + h->out_w, h->out_b, y, (long)N * F * T, (long)F * T, st));
+        for (int k = 0; k < h->n_classes; ++k)          // y is (N, K, F, T): class k is plane k of every clip
+            ADN_HIP(adn::launch_conv_out(X, f16, h->dev + h->out_w + (size_t)64 * k, h->out_bias[k], y + (size_t)k * F * T,
+                                         (long)N * F * T, (long)F * T, (long)h->n_classes * F * T, st));
     ADN_MARK();
     if (timed) {
         if (evi != ADN_N_LAUNCHES + 1) return fail(ADN_ERR_INVALID, "internal: launch count mismatch");
@@ -672,7 +679,7 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
     }
 #undef ADN_MARK
     if (taps && taps[9])
-        ADN_HIP(hipMemcpyAsync(taps[9], y, (size_t)N * F * T * sizeof(float), hipMemcpyDeviceToDevice, st));
+        ADN_HIP(hipMemcpyAsync(taps[9], y, (size_t)N * h->n_classes * F * T * sizeof(float), hipMemcpyDeviceToDevice, st));
     return ADN_OK;
 }
 
@@ -721,7 +728,23 @@ int adn_unet_create(adn_unet **handle, int device, const float *const *t, int n_
 
 int adn_unet_create_ex(adn_unet **handle, int device, const float *const *t, int n_tensors, int dtype)
 {
+    return adn_unet_create_general(handle, device, t, n_tensors, dtype, 1, 1);
+}
+
+int adn_unet_channels(const adn_unet *h, int *in_channels, int *num_classes)
+{
+    if (!h || !in_channels || !num_classes) return fail(ADN_ERR_INVALID, "adn_unet_channels: null argument");
+    *in_channels = h->in_ch;
+    *num_classes = h->n_classes;
+    return ADN_OK;
+}
+
+int adn_unet_create_general(adn_unet **handle, int device, const float *const *t, int n_tensors, int dtype, int in_channels,
+                            int num_classes)
+{
     if (!handle || !t) return fail(ADN_ERR_INVALID, "adn_unet_create: null argument");
+    if (in_channels < 1 || in_channels > 15 || num_classes < 1 || num_classes > 64)
+        return fail(ADN_ERR_INVALID, "adn_unet_create_general: need 1 <= in_channels <= 15 and 1 <= num_classes <= 64");
     if (dtype != ADN_DTYPE_F32 && dtype != ADN_DTYPE_F16) return fail(ADN_ERR_INVALID, "adn_unet_create: dtype must be ADN_DTYPE_F32 or ADN_DTYPE_F16");
     if (n_tensors != ADN_N_WEIGHT_TENSORS) return fail(ADN_ERR_INVALID, "adn_unet_create: expected 118 tensors");
     for (int i = 0; i < n_tensors; ++i)
@@ -738,6 +761,8 @@ int adn_unet_create_ex(adn_unet **handle, int device, const float *const *t, int
 
     adn_unet *h = new adn_unet();
     h->device = device;
+    h->in_ch = in_channels;
+    h->n_classes = num_classes;
     h->f16 = dtype == ADN_DTYPE_F16;
     if (const char *algo = std::getenv("ADN_CONV_ALGO"))       // "direct": implicit-GEMM kernel instead of Winograd
         h->use_wino = std::strcmp(algo, "direct") != 0;
@@ -802,9 +827,11 @@ int adn_unet_create_ex(adn_unet **handle, int device, const float *const *t, int
     // downconv1: first conv has Cin = 1 -> direct kernel, weights [tap][cout]
     {
         bn_fold(t[1], t[2], t[3], t[4], t[5], 64, scale, bias);
-        h->first_w = reserve(9 * 64);
-        for (int tap = 0; tap < 9; ++tap)
-            for (int co = 0; co < 64; ++co) host[h->first_w + tap * 64 + co] = t[0][co * 9 + tap] * scale[co];
+        h->first_w = reserve((size_t)h->in_ch * 9 * 64);              // [input plane][tap][64]
+        for (int ci = 0; ci < h->in_ch; ++ci)
+            for (int tap = 0; tap < 9; ++tap)
+                for (int co = 0; co < 64; ++co)
+                    host[h->first_w + ((size_t)ci * 9 + tap) * 64 + co] = t[0][((size_t)co * h->in_ch + ci) * 9 + tap] * scale[co];
         h->first_b = reserve(64);
         std::memcpy(host.data() + h->first_b, bias.data(), sizeof(float) * 64);
         ti = 6;
@@ -841,8 +868,9 @@ int adn_unet_create_ex(adn_unet **handle, int device, const float *const *t, int
         add_conv3(2 * co, co);
         add_conv3(co, co);
     }
-    h->out_w = reserve(64);
-    std::memcpy(host.data() + h->out_w, t[ti], sizeof(float) * 64);
+    h->out_w = reserve((size_t)64 * h->n_classes);                   // out.weight (K, 64, 1, 1) is already [class][64]
+    std::memcpy(host.data() + h->out_w, t[ti], sizeof(float) * 64 * h->n_classes);
+    h->out_bias.assign(t[ti + 1], t[ti + 1] + h->n_classes);
     h->out_b = t[ti + 1][0];
     ti += 2;
     if (ti != ADN_N_WEIGHT_TENSORS || li != 17) {

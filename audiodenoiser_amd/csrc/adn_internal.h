@@ -153,12 +153,12 @@ hipError_t launch_conv16(ConvKind kind, const ConvArgs &a, bool resident, hipStr
 
 // First layer: Conv2d(1 -> 64, 3x3, pad 1) + folded BN + ReLU, fp32 input, blocked-layout output.  w9x64: [tap][cout].
 hipError_t launch_conv_first(const float *x, const float *w9x64, const float *bias, void *out, bool f16,
-                             int N, int H, int W, hipStream_t st);
+                             int N, int H, int W, int Cin, hipStream_t st);
 // y[i] = bias + sum over `planes` partial planes of CONV3X3_RELU_DOT (fixed order): the tail of the fused last layer.
 hipError_t launch_dot_finish(const float *planes, int nplanes, float bias, float *y, long npix, hipStream_t st);
 // Last layer: Conv2d(64 -> 1, 1x1), fp32 output.
 hipError_t launch_conv_out(const void *in, bool f16, const float *w64, float bias, float *out, long npix, long HW,
-                           hipStream_t st);
+                           long out_stride, hipStream_t st);
 // internal blocked layout -> NCHW fp32 (parity-test export only).
 hipError_t launch_nhwc_to_nchw(const void *in, bool f16, float *out, int N, int H, int W, int C, hipStream_t st);
 

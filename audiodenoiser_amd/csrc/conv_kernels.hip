@@ -730,42 +730,47 @@ constexpr int FIRST_ROWS = 8;
 // One thread = one pixel, all 64 output channels block by block (blocked layout, adn_internal.h).  The 9 weights of each
 // channel are wave-uniform (scalar loads, used as scalar operands of the FMAs), the pixel's 3x3 window is read from LDS once
 // for all blocks, and a wave's two 16-byte stores per block cover 64 neighbouring pixels x 32 bytes = 2 KB contiguous.
+// Cin: input planes of the network (UNet(in_channels, ...), model.py:54,56; 1 in the reference's own callers): the window holds
+// Cin planes, the weights are [plane][tap][64].
 template <typename T>
 __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict__ x, const float *__restrict__ w9x64,
                                                          const float *__restrict__ bias, T *__restrict__ out,
-                                                         int H, int W, int tiles_per_img)
+                                                         int H, int W, int tiles_per_img, int Cin)
 {
     constexpr int BE = ACT_BLOCK<T>, NV = BE / 4;  // channels per block, float4 accumulators per block
-    extern __shared__ float s_win[];               // (FIRST_ROWS+2) rows x (W+2), zero halo
+    extern __shared__ float s_win[];               // Cin x (FIRST_ROWS+2) rows x (W+2), zero halo
     const int n = blockIdx.x / tiles_per_img;
     const int y0 = (blockIdx.x - n * tiles_per_img) * FIRST_ROWS;
-    const int WP = W + 2;
-    const float *xp = x + (long)n * H * W;
-    for (int i = threadIdx.x; i < (FIRST_ROWS + 2) * WP; i += 256) {
-        const int r = i / WP, c = i - r * WP;
+    const int WP = W + 2, PLANE = (FIRST_ROWS + 2) * WP;
+    const float *xp = x + (long)n * Cin * H * W;
+    for (int i = threadIdx.x; i < Cin * PLANE; i += 256) {
+        const int ci = i / PLANE, j = i - ci * PLANE;
+        const int r = j / WP, c = j - r * WP;
         const int yy = y0 + r - 1, xx = c - 1;
-        s_win[i] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? xp[(long)yy * W + xx] : 0.f;
+        s_win[i] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? xp[((long)ci * H + yy) * W + xx] : 0.f;
     }
     __syncthreads();
     const int rows = min(FIRST_ROWS, H - y0);
     const size_t bstr = (size_t)H * W * BE;        // elements between channel blocks
     for (int i = threadIdx.x; i < rows * W; i += 256) {
         const int r = i / W, xx = i - r * W;
-        float v[9];
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) v[dy * 3 + dx] = s_win[(r + dy) * WP + xx + dx];
         T *op = out + (size_t)n * H * W * 64 + ((size_t)(y0 + r) * W + xx) * BE;
 #pragma unroll
         for (int b = 0; b < 64 / BE; ++b) {
             f32x4 a[NV];
 #pragma unroll
             for (int k = 0; k < NV; ++k) a[k] = *reinterpret_cast<const f32x4 *>(bias + b * BE + 4 * k);
+            for (int ci = 0; ci < Cin; ++ci) {                 // (one plane in the reference's configuration)
+                float v[9];
 #pragma unroll
-            for (int t = 0; t < 9; ++t)
+                for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                for (int k = 0; k < NV; ++k) a[k] += *reinterpret_cast<const f32x4 *>(w9x64 + t * 64 + b * BE + 4 * k) * v[t];
+                    for (int dx = 0; dx < 3; ++dx) v[dy * 3 + dx] = s_win[ci * PLANE + (r + dy) * WP + xx + dx];
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) a[k] += *reinterpret_cast<const f32x4 *>(w9x64 + (ci * 9 + t) * 64 + b * BE + 4 * k) * v[t];
+            }
 #pragma unroll
             for (int k = 0; k < NV; ++k) {
                 a[k].x = fmaxf(a[k].x, 0.f); a[k].y = fmaxf(a[k].y, 0.f); a[k].z = fmaxf(a[k].z, 0.f); a[k].w = fmaxf(a[k].w, 0.f);
@@ -786,9 +791,11 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict
 
 // Last layer: Conv2d(64 -> 1, 1x1) (model.py:68,93).  HBM-bound: 16 lanes per pixel read 4 channels each,
 // 4-step xor-shuffle reduction inside the 16-lane group.  Output is always fp32.
+// out_stride: floats between consecutive clips of the output (HW for one class; num_classes * HW when this launch writes one
+// class plane of an (N, K, F, T) result).
 template <typename T>
 __global__ __launch_bounds__(256) void conv_out_kernel(const T *__restrict__ in, const float *__restrict__ w64,
-                                                       float bias, float *__restrict__ out, long npix, long HW)
+                                                       float bias, float *__restrict__ out, long npix, long HW, long out_stride)
 {
     const int q = threadIdx.x & 15;
     const int slot = threadIdx.x >> 4;
@@ -813,7 +820,10 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const T *__restrict__ in,
         s += __shfl_xor(s, 4, 64);
         s += __shfl_xor(s, 2, 64);
         s += __shfl_xor(s, 1, 64);
-        if (q == 0 && pix < npix) out[pix] = s + bias;
+        if (q == 0 && pix < npix) {
+            const long img = pix / HW;
+            out[img * out_stride + (pix - img * HW)] = s + bias;
+        }
     }
 }
 
@@ -973,12 +983,12 @@ hipError_t launch_conv_mfma(ConvKind kind, const ConvArgs &a, bool f16, hipStrea
 }
 
 hipError_t launch_conv_first(const float *x, const float *w9x64, const float *bias, void *out, bool f16,
-                             int N, int H, int W, hipStream_t st)
+                             int N, int H, int W, int Cin, hipStream_t st)
 {
     const int tpi = (H + FIRST_ROWS - 1) / FIRST_ROWS;
     const long blocks = (long)N * tpi;
-    const size_t lds = (size_t)(FIRST_ROWS + 2) * (W + 2) * sizeof(float);
-    if (blocks <= 0 || blocks > 0x7fffffffL || lds > 160 * 1024) return hipErrorInvalidValue;   // W <= 4094
+    const size_t lds = (size_t)Cin * (FIRST_ROWS + 2) * (W + 2) * sizeof(float);
+    if (blocks <= 0 || blocks > 0x7fffffffL || Cin < 1 || lds > 160 * 1024) return hipErrorInvalidValue;   // Cin * (W + 2) <= 4096
     if (lds > 64 * 1024) {
         const void *fn = f16 ? reinterpret_cast<const void *>(conv_first_kernel<_Float16>)
                              : reinterpret_cast<const void *>(conv_first_kernel<float>);
@@ -987,25 +997,25 @@ hipError_t launch_conv_first(const float *x, const float *w9x64, const float *bi
     }
     if (f16)
         hipLaunchKernelGGL(conv_first_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), lds, st, x, w9x64, bias,
-                           static_cast<_Float16 *>(out), H, W, tpi);
+                           static_cast<_Float16 *>(out), H, W, tpi, Cin);
     else
         hipLaunchKernelGGL(conv_first_kernel<float>, dim3((unsigned)blocks), dim3(256), lds, st, x, w9x64, bias,
-                           static_cast<float *>(out), H, W, tpi);
+                           static_cast<float *>(out), H, W, tpi, Cin);
     return hipGetLastError();
 }
 
 hipError_t launch_conv_out(const void *in, bool f16, const float *w64, float bias, float *out, long npix, long HW,
-                           hipStream_t st)
+                           long out_stride, hipStream_t st)
 {
     if (HW <= 0 || npix % HW) return hipErrorInvalidValue;
     long blocks = (npix + 15) / 16;
     if (blocks > 256L * 32) blocks = 256L * 32;
     if (f16)
         hipLaunchKernelGGL(conv_out_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), 0, st,
-                           static_cast<const _Float16 *>(in), w64, bias, out, npix, HW);
+                           static_cast<const _Float16 *>(in), w64, bias, out, npix, HW, out_stride);
     else
         hipLaunchKernelGGL(conv_out_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st,
-                           static_cast<const float *>(in), w64, bias, out, npix, HW);
+                           static_cast<const float *>(in), w64, bias, out, npix, HW, out_stride);
     return hipGetLastError();
 }
 

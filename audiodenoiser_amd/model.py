@@ -2,7 +2,7 @@
 
 Mirrors the public surface of ``/root/reference/code/model.py``: ``UNet(in_channels=1, num_classes=1)`` is an
 ``nn.Module`` with the reference's exact parameter tree (136 ``state_dict`` entries, strict-loadable from a
-reference checkpoint, ``test.py:65``), and ``forward(x: (N,1,F,T) float32) -> (N,1,F,T) float32``
+reference checkpoint, ``test.py:65``), and ``forward(x: (N,C,F,T) float32) -> (N,K,F,T) float32``
 (``model.py:70-94``).  The arithmetic does NOT go through ATen: ``forward`` hands raw device pointers and the
 current PyTorch-ROCm stream to ``libadn.so`` (``include/adn.h``).
 
@@ -70,9 +70,13 @@ class UpSampleLayer(_ParamsOnly):
 class UNet(nn.Module):
     def __init__(self, in_channels: int = 1, num_classes: int = 1):
         super().__init__()
-        if in_channels != 1 or num_classes != 1:
-            raise ValueError("the MI355X path implements the reference configuration UNet(1, 1) (test.py:63)")
+        if not (1 <= in_channels <= 15 and 1 <= num_classes <= 64):
+            raise ValueError("UNet(in_channels, num_classes): the MI355X path takes 1..15 input planes and 1..64 classes "
+                             "(reference configuration: UNet(1, 1), test.py:63)")
+        self.in_channels, self.num_classes = in_channels, num_classes
         for (name, cin, cout) in DOUBLE_CONVS:
+            if name == "downconv1.conv":
+                cin = in_channels
             top = name.split(".")[0]
             if top.startswith("downconv"):
                 setattr(self, top, DownSampleLayer(cin, cout))
@@ -140,8 +144,9 @@ class UNet(nn.Module):
         table = (_lib.c_float_p * len(host))(*[ctypes.cast(t.data_ptr(), _lib.c_float_p) for t in host])
         handle = ctypes.c_void_p()
         with torch.cuda.device(device):
-            _lib.check(L.adn_unet_create_ex(ctypes.byref(handle), device.index, table, len(host),
-                                            1 if self._compute_dtype == "f16" else 0), "adn_unet_create_ex")
+            _lib.check(L.adn_unet_create_general(ctypes.byref(handle), device.index, table, len(host),
+                                                 1 if self._compute_dtype == "f16" else 0, self.in_channels, self.num_classes),
+                       "adn_unet_create_general")
         self._handle = handle
         self._handle_key = key
         return handle
@@ -165,8 +170,8 @@ class UNet(nn.Module):
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             raise RuntimeError("audiodenoiser_amd.UNet: the HIP forward records no autograd graph; wrap the call in "
                                "torch.no_grad() as the reference's test.py:112 / train.py:80 do")
-        if x.dim() != 4 or x.shape[1] != 1:
-            raise ValueError(f"expected input (N, 1, F, T), got {tuple(x.shape)}")
+        if x.dim() != 4 or x.shape[1] != self.in_channels:
+            raise ValueError(f"expected input (N, {self.in_channels}, F, T), got {tuple(x.shape)}")
         if x.shape[2] < 16 or x.shape[3] < 16:
             raise ValueError("F and T must be >= 16 (four 2x poolings)")
         if x.dtype != torch.float32:
@@ -184,7 +189,7 @@ class UNet(nn.Module):
         dev = x.device
         handle = self._ensure_handle(dev)
         ws = self._workspace_for(n, f, t, dev)
-        y = torch.empty_like(x)
+        y = torch.empty((n, self.num_classes, f, t), dtype=torch.float32, device=dev)
         L = _lib.load()
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
@@ -199,7 +204,7 @@ class UNet(nn.Module):
                 hs.append(hs[-1] // 2)
                 wsz.append(wsz[-1] // 2)
             shapes = [(n, ch[l], hs[l], wsz[l]) for l in range(4)] + [(n, 1024, hs[4], wsz[4])]
-            shapes += [(n, ch[l], hs[l], wsz[l]) for l in (3, 2, 1, 0)] + [(n, 1, f, t)]
+            shapes += [(n, ch[l], hs[l], wsz[l]) for l in (3, 2, 1, 0)] + [(n, self.num_classes, f, t)]
             taps = [torch.empty(s, dtype=torch.float32, device=dev) for s in shapes]
             arr = (ctypes.c_void_p * 10)(*[tp.data_ptr() for tp in taps])
             _lib.check(L.adn_unet_forward_taps(handle, x.data_ptr(), y.data_ptr(), n, f, t, ws.data_ptr(), ws.numel(),

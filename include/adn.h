@@ -76,13 +76,22 @@ int adn_unet_create(adn_unet **handle, int device, const float *const *host_tens
 #define ADN_DTYPE_F32 0
 #define ADN_DTYPE_F16 1
 int adn_unet_create_ex(adn_unet **handle, int device, const float *const *host_tensors, int n_tensors, int dtype);
+/* UNet(in_channels, num_classes) as the reference declares it (code/model.py:54,56,68; its own callers use (1, 1), test.py:63):
+ * the same 118 tensors with downconv1.conv.double_conv.0.weight (64, in_channels, 3, 3), out.weight (num_classes, 64, 1, 1) and
+ * out.bias (num_classes).  x is then (N, in_channels, F, T) and y (N, num_classes, F, T), both NCHW fp32.  1 <= in_channels <= 15
+ * (and in_channels * (T + 2) <= 4096), 1 <= num_classes <= 64.  With more than one input plane / class the first / last
+ * convolution run as their own launches (the fused forms are for one plane / one class). */
+int adn_unet_create_general(adn_unet **handle, int device, const float *const *host_tensors, int n_tensors, int dtype,
+                            int in_channels, int num_classes);
+int adn_unet_channels(const adn_unet *handle, int *in_channels, int *num_classes);
 int adn_unet_destroy(adn_unet *handle);
 
 /* Bytes of device scratch adn_unet_forward needs for an (N,1,F,T) batch (half as much for an fp16 handle;
  * handle may be NULL = fp32). */
 int adn_unet_workspace_bytes(const adn_unet *handle, int N, int F, int T, size_t *bytes);
 
-/* y(N,1,F,T) = UNet(x(N,1,F,T)), eval-mode semantics (BatchNorm uses running statistics), fp32.
+/* y(N,K,F,T) = UNet(x(N,C,F,T)) (C = K = 1 unless the handle came from adn_unet_create_general), eval-mode semantics
+ * (BatchNorm uses running statistics), fp32.
  * x, y, workspace: device memory on the handle's device.  F,T >= 16 (four 2x poolings). */
 /* Shape limits: N >= 1, F >= 16, 16 <= T <= 4094, F*T < 2^24 (ADN_ERR_INVALID otherwise). */
 int adn_unet_forward(adn_unet *handle, const float *x, float *y, int N, int F, int T,

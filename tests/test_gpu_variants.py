@@ -173,3 +173,34 @@ def test_convt_split_extreme_operands(dev, weights_np, monkeypatch):
         te = exact(x * 4.0, return_taps=True)[1]
         split(x * 4.0)
     assert bool(torch.isinf(te["bottleneck"]).any())
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", TOL), ("f16", 1e-2)])
+def test_unet_two_input_planes_three_classes(dev, golden_dir, dtype, tol, monkeypatch):
+    """UNet(in_channels=2, num_classes=3) as the reference declares it (model.py:54,56,68): golden from the reference's own
+    forward (unet_c2k3_33x47.npz); first / last convolution as their own launches, every block tap checked."""
+    from audiodenoiser_amd.model import UNet
+    from audiodenoiser_amd.weights import make_input, make_state_dict
+    for k in ENV_KEYS:
+        monkeypatch.delenv(k, raising=False)
+    g = np.load(os.path.join(golden_dir, "unet_c2k3_33x47.npz"))
+    sd = make_state_dict(1234, 2, 3)
+    m = UNet(2, 3)
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, strict=True)
+    m = m.to(dev).eval().set_compute_dtype(dtype)
+    x = torch.from_numpy(make_input(7, 4, 33, 47).reshape(2, 2, 33, 47)).to(dev)
+    with torch.no_grad():
+        y, taps = m(x, return_taps=True)
+        y_plain = m(x)
+        one = m(x[1:2].clone())
+    assert tuple(y.shape) == (2, 3, 33, 47) and tuple(taps["out"].shape) == (2, 3, 33, 47)
+    for got in (y, y_plain, taps["out"]):
+        assert _rel(got.cpu().numpy(), g["y"]) <= tol
+    assert _rel(one.cpu().numpy()[0], g["y"][1]) <= tol
+    for name, tp in taps.items():
+        a = tp.cpu().numpy().astype(np.float64).ravel()
+        s_, sa, sq, cnt = g[f"{name}_stats"]
+        assert a.size == int(cnt), name
+        assert np.abs(a[g[f"{name}_idx"]] - g[f"{name}_val"]).max() <= (10 * tol if dtype == "f32" else 5 * tol) * np.sqrt(sq / cnt), name
+    with torch.no_grad(), pytest.raises(ValueError):
+        m(torch.zeros((1, 1, 33, 47), device=dev))                # one plane into a two-plane network

@@ -70,7 +70,17 @@ def test_model_parameter_tree_and_guards(weights_np):
     with torch.no_grad(), pytest.raises(RuntimeError, match="ROCm device"):
         m(torch.zeros(1, 1, 16, 16))
     with pytest.raises(ValueError):
-        UNet(3, 1)
+        UNet(16, 1)                                       # 1..15 input planes, 1..64 classes
+    with pytest.raises(ValueError):
+        UNet(1, 0)
+    # UNet(in_channels, num_classes) as the reference declares it (model.py:54,56,68): same 136 keys, two shapes differ
+    m23 = UNet(2, 3)
+    sd23 = m23.state_dict()
+    schema23 = state_dict_schema(2, 3)
+    assert list(sd23.keys()) == list(schema23.keys())
+    for k, v in sd23.items():
+        assert tuple(v.shape) == tuple(schema23[k]), k
+    assert tuple(sd23["downconv1.conv.double_conv.0.weight"].shape) == (64, 2, 3, 3) and tuple(sd23["out.weight"].shape) == (3, 64, 1, 1)
 
 
 def test_dataset_mirror_matches_reference_golden(tmp_path, golden_dir, capsys):

@@ -150,3 +150,15 @@ def test_weight_variants_are_what_they_claim(variant_weights):
     w = hv["bottleneck.double_conv.3.weight"].ravel()
     bound = np.sqrt(6.0 / (1024 * 9))
     assert (np.abs(w) > 5 * bound).sum() in range(1, 9)               # the 8 outliers (fewer if two hashes collide / tiny values)
+
+
+def test_torch_oracle_matches_reference_golden_two_planes_three_classes(golden_dir):
+    """UNet(in_channels=2, num_classes=3) (model.py:54,56,68; tools/make_golden.py --only channels)."""
+    from audiodenoiser_amd.weights import make_state_dict
+    g = np.load(os.path.join(golden_dir, "unet_c2k3_33x47.npz"))
+    sd = unet_torch.to_torch_state(make_state_dict(1234, 2, 3))
+    x = torch.from_numpy(make_input(7, 4, 33, 47).reshape(2, 2, 33, 47))
+    y, taps = unet_torch.unet_forward(sd, x, want_taps=True)
+    assert tuple(y.shape) == (2, 3, 33, 47)
+    assert np.abs(y.numpy() - g["y"]).max() <= 1e-6 * np.abs(g["y"]).max()
+    _check_taps(g, {k: v.numpy() for k, v in taps.items()}, 1e-6)

@@ -20,6 +20,7 @@ What is frozen:
 * ``unet_{trained,heavy}_<F>x<T>.npz`` (``--only variants``) — the reference forward under two more seeded parameter sets
   (``audiodenoiser_amd.weights.make_state_dict_variant``: trained-like BatchNorm statistics / heavy-tailed weights) on the
   real-audio input above cropped to (F, T), two clips at scale 1 and 100.
+* ``unet_c2k3_33x47.npz`` (``--only channels``) — the reference's ``UNet(in_channels=2, num_classes=3)`` on a seeded input.
 * ``loss_cases.npz`` (``--only loss``) — the reference's ``MultiScaleSTFTLoss`` (``code/loss.py:6-35``) and ``nn.L1Loss``
   (``loss.py:75,86``) on three seeded (B, 1, F, T) pairs.  The mel term needs torchaudio (absent): not frozen, parity unpinned.
 """
@@ -136,6 +137,42 @@ def weight_variants() -> None:
             print(f"wrote {path} ({os.path.getsize(path)} B): y mean {float(y.mean()):+.4g} std {float(y.std()):.4g}; max|tap|: " + ", ".join(line))
 
 
+def channels_case() -> None:
+    """``unet_c2k3_33x47.npz``: the reference's ``UNet(in_channels=2, num_classes=3)`` (code/model.py:54,56,68 accept any; its own
+    callers use (1, 1)) on a seeded (2, 2, 33, 47) input: full output (2, 3, 33, 47) + the block statistics of the other goldens."""
+    import model as ref_model  # reference code/model.py
+
+    torch.set_num_threads(os.cpu_count() or 1)
+    net = ref_model.UNet(in_channels=2, num_classes=3)
+    sd = make_state_dict(WEIGHT_SEED, 2, 3)
+    net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, strict=True)
+    net.eval()
+    acts = {}
+
+    def hook(name):
+        def fn(_mod, _inp, out):
+            acts[name] = (out[0] if isinstance(out, tuple) else out).detach()
+        return fn
+
+    for mod_name in REF_MODULES:
+        getattr(net, mod_name).register_forward_hook(hook(mod_name))
+    n, f, t = 2, 33, 47
+    x = torch.from_numpy(make_input(INPUT_SEED, n * 2, f, t).reshape(n, 2, f, t))
+    with torch.no_grad():
+        y = net(x)
+    rec = {"y": y.numpy().astype(np.float32), "shape": np.array([n, 2, 3, f, t]), "weight_seed": np.array(WEIGHT_SEED),
+           "input_seed": np.array(INPUT_SEED)}
+    for mod_name, key in zip(REF_MODULES, TAP_KEYS):
+        a = acts[mod_name].numpy().astype(np.float64).ravel()
+        idx = sample_indices(key, a.size)
+        rec[f"{key}_stats"] = np.array([a.sum(), np.abs(a).sum(), (a * a).sum(), a.size], dtype=np.float64)
+        rec[f"{key}_idx"] = idx
+        rec[f"{key}_val"] = a[idx].astype(np.float32)
+    path = os.path.join(GOLDEN, "unet_c2k3_33x47.npz")
+    np.savez_compressed(path, **rec)
+    print(f"wrote {path}: y{tuple(y.shape)} mean {float(y.mean()):+.4f} std {float(y.std()):.4f}")
+
+
 LOSS_CASES = ((3, 40, 96), (2, 257, 188), (2, 513, 256))
 
 
@@ -178,6 +215,8 @@ def main() -> None:
         return config0_real_audio()
     if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "loss":
         return loss_cases()
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "channels":
+        return channels_case()
     if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "variants":
         return weight_variants()
     import data_loader as ref_loader  # reference code/data_loader.py
@@ -245,6 +284,7 @@ def main() -> None:
     config0_real_audio()
     weight_variants()
     loss_cases()
+    channels_case()
 
 
 if __name__ == "__main__":
