@@ -33,11 +33,6 @@ __device__ __forceinline__ void dma16_buf(__amdgpu_buffer_rsrc_t rsrc, unsigned 
 {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)lds_wave_base, 16, voff, soff, 0, 0);
 }
-// the same with the non-temporal hint (aux = 2): for bytes a CU reads once
-__device__ __forceinline__ void dma16_buf_nt(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, float *lds_wave_base)
-{
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)lds_wave_base, 16, voff, soff, 0, 2);
-}
 // descriptor over `bytes` bytes at `base` (both wave-uniform)
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t dma_rsrc(const void *base, unsigned bytes)
 {

@@ -47,9 +47,6 @@ constexpr int C16_W_SLOTS = 9 * 4 * 64;           // weight slab of a chunk: [ta
 constexpr int C16_HPIECES = C16_HALO_SLOTS / 64 / 8;       // halo copies per wave and chunk (5)
 constexpr int C16_WPIECES = (C16_W_SLOTS / 64 + 7) / 8;    // weight copies per wave and chunk (5, the last half used)
 
-#ifndef C16_PRIO                                  // 0 = none, 1 = static s_setprio 1 for waves 4-7, 2 = alternating per tap
-#define C16_PRIO 0
-#endif
 #ifndef C16_PPT
 #define C16_PPT 2                                 // copies issued per tap (from tap 0 on)
 #endif
@@ -108,15 +105,12 @@ __device__ __forceinline__ C16Item c16_decode(const ConvArgs &p, int id)
 
 // EPI: CONV3X3_RELU / CONV3X3_RELU_POOL / CONV3X3_RELU_DOT (adn_internal.h).  WRES: weights resident in LDS (nchunk <= 2, nct == 1).
 // FIRST: see C16Lds (needs WRES; p.s0.ptr = the network input (N,1,H,W) fp32, p.firstw [9][64] / p.firstb [64] fp32).
-// RS: the halo is staged through REGISTERS two steps ahead (buffer_load -> VGPRs during step s, ds_write into the free image at the
-// end of step s + 1, consumed in step s + 2) instead of by LDS-DMA one step ahead: the full-resolution layers read their halos
-// from HBM, and a copy issued one 4-us step ahead was still being awaited for 1 300-2 700 clocks of every step
-// (profiles/r04_conv16_timeline.txt).  40 VGPRs; the weights of the streamed form stay on LDS-DMA (L2 hits).
-template <int EPI, bool WRES, bool FIRST = false, bool RS = false>
+// (A variant staging the halo through registers two steps ahead, a ct-slowest item order, non-temporal halo copies and wave
+// priorities were measured and removed: profiles/NOTES.md round 4, commits f561295 / 157a27f / 77e5780.)
+template <int EPI, bool WRES, bool FIRST = false>
 __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
 {
     static_assert(!FIRST || WRES, "the fused first layer feeds a 64 -> 64 layer");
-    static_assert(!(FIRST && RS), "the fused first layer has no halo to stage");
     using L = C16Lds<WRES, FIRST>;
     constexpr int WIN_OFF = (L::RES_SLOTS + 2 * L::IMG_SLOTS) * 16;
     constexpr int IMG_B = L::IMG_SLOTS * 16;                   // bytes per image
@@ -156,13 +150,13 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
     // descriptors are rebuilt from scalars at every use (two SALU operations) instead of being carried through the loop
     const char *hbase = nullptr;                    // image of clip n in the current source
     unsigned himg_bytes = 0, hblk_bytes = 0;        // bytes of that image / of one of its channel blocks (H * W * 32)
-    auto plan = [&](const ConvSrc &s, const C16Item &it, bool exists = true) {
+    auto plan = [&](const ConvSrc &s, const C16Item &it) {
         const int gy0 = it.ty * C16_TH - 1 - s.offY, gx0 = it.tx * C16_TW - 1 - s.offX;
 #pragma unroll
         for (int k = 0; k < C16_HPIECES; ++k) {
             const int y = gy0 + prow[k], x = gx0 + (ppx[k] & 0xffff);
             const unsigned off = (unsigned)((y * s.W + x) * 32 + (ppx[k] >> 16) * 16);
-            hcur[k] = (exists && y >= 0 && y < s.H && x >= 0 && x < s.W) ? off : ADN_DMA_OOB;     // (beyond the last item: loads of nothing)
+            hcur[k] = (y >= 0 && y < s.H && x >= 0 && x < s.W) ? off : ADN_DMA_OOB;
         }
         himg_bytes = (unsigned)(s.C * s.H * s.W) * 2u;
         hblk_bytes = (unsigned)(s.H * s.W) * 32u;
@@ -250,7 +244,7 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
             if (valid) *reinterpret_cast<f16x4 *>(dst + jb * (C16_BLK_SLOTS * 16)) = hv;
         }
     };
-    // weights of the streamed form: their own fetch state, always one step ahead (with RS the halo state runs two ahead)
+    // weights of the streamed form: their own fetch state, one step ahead
     int w_item = first, w_chunk = 0, w_ct = fi.ct;
     auto w_advance = [&]() {
         if (++w_chunk == nchunk) {
@@ -259,9 +253,6 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
             if (w_item < nitems) w_ct = c16_decode(p, w_item).ct;
         }
     };
-    // RS: register sets of the halo (set = parity of the step the loads are issued in)
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 hreg[RS ? 2 : 1][C16_HPIECES];
     auto halo_rsrc = [&]() {
         const unsigned long long hb = reinterpret_cast<unsigned long long>(hbase);
         const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)hb);
@@ -272,18 +263,6 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
         const int blk = 8 * q + wave >= 20 ? 1 : 0;
         const int cl = f_chunk < p.nchunk0 ? f_chunk : f_chunk - p.nchunk0;          // chunk inside the current source
         return (unsigned)__builtin_amdgcn_readfirstlane((2 * cl + blk) * (int)hblk_bytes);
-    };
-    auto halo_load = [&](auto set_tag) {            // the halo of the fetch step into register set SET
-        constexpr int SET = decltype(set_tag)::value;
-        const __amdgpu_buffer_rsrc_t rs = halo_rsrc();
-#pragma unroll
-        for (int q = 0; q < C16_HPIECES; ++q) hreg[RS ? SET : 0][q] = __builtin_amdgcn_raw_buffer_load_b128(rs, hcur[q], halo_soff(q), 0);
-    };
-    auto halo_store = [&](auto set_tag, int buf) {  // register set SET into the halo part of image `buf` (the slots the copies would fill)
-        constexpr int SET = decltype(set_tag)::value;
-#pragma unroll
-        for (int q = 0; q < C16_HPIECES; ++q)
-            *reinterpret_cast<u32x4 *>(img_base + buf * IMG_B + (8 * q + wave) * 1024 + lane * 16) = hreg[RS ? SET : 0][q];
     };
     // piece q (0 .. NPIECE-1) of the fetch step into image `buf`
     auto fetch_piece = [&](int q, int buf) {
@@ -296,11 +275,7 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
         } else if (q < C16_HPIECES) {
             // (descriptor words through readfirstlane, halo_rsrc: they are wave-uniform, but hipcc keeps loop-carried scalars in VGPRs
             // when it runs short of SGPRs, and a descriptor in VGPRs makes every copy a waterfall loop)
-#ifdef C16_HALO_NT
-            if constexpr (!RS) dma16_buf_nt(halo_rsrc(), hcur[q], halo_soff(q), reinterpret_cast<float *>(img + (8 * q + wave) * 1024));
-#else
-            if constexpr (!RS) dma16_buf(halo_rsrc(), hcur[q], halo_soff(q), reinterpret_cast<float *>(img + (8 * q + wave) * 1024));
-#endif
+            dma16_buf(halo_rsrc(), hcur[q], halo_soff(q), reinterpret_cast<float *>(img + (8 * q + wave) * 1024));
         } else if (!WRES) {
             const int pi = 8 * (q - C16_HPIECES) + wave;             // 0 .. 39: the slab has 36 pieces, piece 36 carries the biases
             if (pi < C16_W_SLOTS / 64) {
@@ -320,8 +295,6 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
             if (f_item < nitems) {
                 fi = c16_decode(p, f_item);
                 if constexpr (!FIRST) plan(p.s0, fi);
-            } else if constexpr (RS) {
-                plan(p.s0, fi, false);
             }
         } else if (f_chunk == p.nchunk0) {
             if constexpr (!FIRST) plan(p.s1, fi);   // virtual concat: the second source (with its pad offset)
@@ -345,23 +318,10 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    if constexpr (RS) {
-        // halo of step 0 through registers into image 0, halo of step 1 into set 1 (written at the end of step 0); weights of step 0
-        halo_load(std::integral_constant<int, 0>{});
-        fetch_advance();
 #pragma unroll
-        for (int q = C16_HPIECES; q < NPIECE; ++q) fetch_piece(q, 0);
-        if constexpr (!WRES) w_advance();
-        halo_store(std::integral_constant<int, 0>{}, 0);
-        if (nsteps == 1) plan(p.s0, fi, false);
-        halo_load(std::integral_constant<int, 1>{});
-        fetch_advance();
-    } else {
-#pragma unroll
-        for (int q = 0; q < NPIECE; ++q) fetch_piece(q, 0);
-        fetch_advance();
-        if constexpr (!WRES && !FIRST) w_advance();
-    }
+    for (int q = 0; q < NPIECE; ++q) fetch_piece(q, 0);
+    fetch_advance();
+    if constexpr (!WRES && !FIRST) w_advance();
 
     // ---- compute side ----
     int c_item = first, c_chunk = 0, c_k = 0;
@@ -378,8 +338,7 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
         for (int j = 0; j < 4; ++j) dotw_r[j] = *reinterpret_cast<const f32x4 *>(p.dotw + 16 * j + 4 * g);
     }
 
-    if constexpr (RS) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");      // the five loads of step 1's halo stay in flight
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
 #ifdef ADN_EXPERIMENTS
@@ -388,7 +347,7 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
     const bool tl_on = p.dbg != nullptr;
     unsigned long long tl_c = 0, tl_sum[3] = {0, 0, 0}, tl_0 = tl_on ? __builtin_amdgcn_s_memtime() : 0, tl_first = tl_0;
 #endif
-    // one step = one 32-channel chunk of one item; PAR = parity of the step (selects the RS register set at compile time)
+    // one step = one 32-channel chunk of one item; PAR = parity of the step = the LDS image it computes from
     auto step = [&](auto par_tag, const int s) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par_tag)::value;
         const int buf = PAR;
@@ -446,28 +405,13 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
             }
             // the next step's copies go out between the first taps' MFMA groups (PPT per tap): the last one has the rest of
             // the step to land before the wait at its end
-            if constexpr (RS) {
-                // weights of the next step first, then the halo of the step after it into registers: in issue order the loads
-                // are the youngest, so the wait at the end of the step can leave exactly them in flight
-                if (more) {
-#pragma unroll
-                    for (int q = C16_HPIECES + tp * PPT; q < C16_HPIECES + (tp + 1) * PPT; ++q)
-                        if (q < NPIECE) fetch_piece(q, buf ^ 1);
-                }
-                if (tp == (WRES ? 0 : 3)) halo_load(std::integral_constant<int, PAR>{});
-            } else if (more && !(abl & 2)) {
+            if (more && !(abl & 2)) {
 #pragma unroll
                 for (int q = tp * PPT; q < (tp + 1) * PPT; ++q)
                     if (q < NPIECE) fetch_piece(q, buf ^ 1);
             }
 #ifdef ADN_EXPERIMENTS
             if (tp == 8 && tl_on) tl_c = __builtin_amdgcn_s_memtime();
-#endif
-#if C16_PRIO == 2
-            // the two waves of a SIMD (w, w + 4) take turns at the higher priority, tap by tap: the arbitration otherwise favours
-            // the older wave all step long and the younger one finishes its MFMAs alone, at a single wave's issue rate
-            if (((tp + (wave >> 2)) & 1)) __builtin_amdgcn_s_setprio(1);
-            else __builtin_amdgcn_s_setprio(0);
 #endif
             if (!(abl & 1)) {
 #pragma unroll
@@ -477,10 +421,7 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tp & 1][j], xr[dx & 1][i + dy], acc[i][j], 0, 0, 0);
             }
         }
-        if constexpr (RS) {
-            fetch_advance();                           // (the halo state runs two steps ahead, past the last step too: loads of nothing)
-            if constexpr (!WRES) if (more) w_advance();
-        } else if (more) {
+        if (more) {
             fetch_advance();
             if constexpr (!WRES && !FIRST) w_advance();
         }
@@ -573,19 +514,12 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
             // for the stores.  Every LDS read of this step has been consumed by an MFMA, and the copies into the other image were
             // awaited just above, so the bare barrier orders everything the next step relies on.)
             __builtin_amdgcn_sched_barrier(0);
-            // (RS: + the five halo loads of this step, issued behind the copies)
-            if constexpr (NST + (RS ? 5 : 0) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else if constexpr (NST + (RS ? 5 : 0) == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-            else if constexpr (NST + (RS ? 5 : 0) == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            else if constexpr (NST + (RS ? 5 : 0) == 21) asm volatile("s_waitcnt vmcnt(21)" ::: "memory");
-            else if constexpr (NST + (RS ? 5 : 0) == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(29)" ::: "memory");
+            if constexpr (NST == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if constexpr (NST == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
         } else {
-            if constexpr (RS) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        // RS: the halo of the NEXT step (loaded during the previous one) goes into the image the barrier below hands over
-        if constexpr (RS) halo_store(std::integral_constant<int, PAR ^ 1>{}, buf ^ 1);
         if constexpr (FIRST) {
             if (win_pending) win_write((c_k + 1) & 1);     // (the loads are older than this step's stores: the compiler's wait leaves those in flight)
         }
@@ -616,7 +550,7 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
 #endif
 }
 
-template <int EPI, bool WRES, bool FIRST = false, bool RS = false>
+template <int EPI, bool WRES, bool FIRST = false>
 hipError_t launch_c16(const ConvArgs &a, hipStream_t st)
 {
     using L = C16Lds<WRES, FIRST>;
@@ -651,7 +585,7 @@ hipError_t launch_c16(const ConvArgs &a, hipStream_t st)
         cus.store(c, std::memory_order_relaxed);
     }
     long grid = nitems < c ? ((nitems + 7) & ~7L) : c;   // one resident workgroup per CU walks the items
-    auto kern = conv16_f16<EPI, WRES, FIRST, RS>;
+    auto kern = conv16_f16<EPI, WRES, FIRST>;
     static std::atomic<unsigned long long> attr_mask{0};
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(attr_mask.load(std::memory_order_acquire) & bit)) {
@@ -707,26 +641,6 @@ hipError_t launch_conv16(ConvKind kind, const ConvArgs &a, bool resident, hipStr
     if (!conv16_applicable(kind, a)) return hipErrorInvalidValue;
     if (resident && (a.nchunk > 2 || a.Cout != 64)) return hipErrorInvalidValue;
     if (a.firstw) return (resident && a.nchunk == 2) ? launch_c16<CONV3X3_RELU_POOL, true, true>(a, st) : hipErrorInvalidValue;
-    // register-staged halos two steps ahead (RS): measured 2-6 % SLOWER than the one-step-ahead copies on every layer
-    // (profiles/r04_conv16_rs_ab.txt) -- the wait for the copies is a throughput limit, not latency.  Experiments builds only.
-#ifdef ADN_EXPERIMENTS
-    static const bool rs = []() { const char *e = std::getenv("ADN_C16_RS"); return e && std::atoi(e) != 0; }();
-#else
-    constexpr bool rs = false;
-#endif
-#ifdef ADN_EXPERIMENTS
-    if (rs) {
-        if (resident) {
-            if (kind == CONV3X3_RELU_DOT) return launch_c16<CONV3X3_RELU_DOT, true, false, true>(a, st);
-            if (kind == CONV3X3_RELU_POOL) return launch_c16<CONV3X3_RELU_POOL, true, false, true>(a, st);
-            return launch_c16<CONV3X3_RELU, true, false, true>(a, st);
-        }
-        if (kind == CONV3X3_RELU_DOT) return launch_c16<CONV3X3_RELU_DOT, false, false, true>(a, st);
-        if (kind == CONV3X3_RELU_POOL) return launch_c16<CONV3X3_RELU_POOL, false, false, true>(a, st);
-        return launch_c16<CONV3X3_RELU, false, false, true>(a, st);
-    }
-#endif
-    (void)rs;
     if (resident) {
         if (kind == CONV3X3_RELU_DOT) return launch_c16<CONV3X3_RELU_DOT, true>(a, st);
         if (kind == CONV3X3_RELU_POOL) return launch_c16<CONV3X3_RELU_POOL, true>(a, st);
