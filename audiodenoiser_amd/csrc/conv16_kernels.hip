@@ -85,17 +85,8 @@ __device__ __forceinline__ C16Item c16_decode(const ConvArgs &p, int id)
 {
     C16Item it;
     id = __builtin_amdgcn_readfirstlane(id);
-    int q1;
-    if (p.pair) {                                  // (ConvArgs::pair reused as the item order) cout tile SLOWEST: every resident
-        // workgroup works on the same cout tile at the same time, so its weights (Cin x 64 x 9 halfs: at most 1.2 MB) stay in every
-        // XCD's L2 however far the workgroups drift apart, and only the halos stream from beyond it
-        const int ct = fastdiv(id, p.fdNcg.d, p.fdNcg.m);          // fdNcg = tiles per cout tile
-        it.ct = __builtin_amdgcn_readfirstlane(ct);
-        q1 = id - ct * (int)p.fdNcg.d;
-    } else {
-        q1 = fastdiv(id, p.fdGc.d, p.fdGc.m);
-        it.ct = __builtin_amdgcn_readfirstlane(id - q1 * p.nct);
-    }
+    const int q1 = fastdiv(id, p.fdGc.d, p.fdGc.m);
+    it.ct = __builtin_amdgcn_readfirstlane(id - q1 * p.nct);
     const int q2 = fastdiv(q1, p.fdTx.d, p.fdTx.m);
     it.tx = __builtin_amdgcn_readfirstlane(q1 - q2 * p.tilesX);
     it.n = __builtin_amdgcn_readfirstlane(fastdiv(q2, p.fdTy.d, p.fdTy.m));
@@ -156,7 +147,7 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
         for (int k = 0; k < C16_HPIECES; ++k) {
             const int y = gy0 + prow[k], x = gx0 + (ppx[k] & 0xffff);
             const unsigned off = (unsigned)((y * s.W + x) * 32 + (ppx[k] >> 16) * 16);
-            hcur[k] = (y >= 0 && y < s.H && x >= 0 && x < s.W) ? off : ADN_DMA_OOB;
+            hcur[k] = (((unsigned)y < (unsigned)s.H) & ((unsigned)x < (unsigned)s.W)) ? off : ADN_DMA_OOB;     // (& not &&: no branches)
         }
         himg_bytes = (unsigned)(s.C * s.H * s.W) * 2u;
         hblk_bytes = (unsigned)(s.H * s.W) * 32u;
@@ -189,7 +180,7 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
             const int e = tid + k * C16_NT;
             const int wr = e / C16_WIN_COLS, wc = e - wr * C16_WIN_COLS;
             const int gy = it.ty * C16_TH - 2 + wr, gx = it.tx * C16_TW - 2 + wc;
-            const unsigned off = (e < C16_WIN_N && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) ? (unsigned)((gy * p.W + gx) * 4) : ADN_DMA_OOB;
+            const unsigned off = ((e < C16_WIN_N) & ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W)) ? (unsigned)((gy * p.W + gx) * 4) : ADN_DMA_OOB;
             wl[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, off, 0, 0));
         }
     };
@@ -233,7 +224,7 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
         const bool odd = g & 1;
         const f16x8 xf = {odd ? t[8] : t[0], odd ? z : t[1], odd ? z : t[2], odd ? z : t[3], odd ? z : t[4], odd ? z : t[5], odd ? z : t[6], odd ? z : t[7]};
         const int gy = fi.ty * C16_TH - 1 + row, gx = fi.tx * C16_TW - 1 + px;
-        const bool inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        const bool inside = ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W);
         char *dst = img_base + buf * IMG_B + row * C16_ROWB + px * 32 + g * 8;
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb) {
@@ -242,15 +233,6 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
 #pragma unroll
             for (int r = 0; r < 4; ++r) hv[r] = inside ? (_Float16)relu_keep_nan(a[r]) : z;
             if (valid) *reinterpret_cast<f16x4 *>(dst + jb * (C16_BLK_SLOTS * 16)) = hv;
-        }
-    };
-    // weights of the streamed form: their own fetch state, one step ahead
-    int w_item = first, w_chunk = 0, w_ct = fi.ct;
-    auto w_advance = [&]() {
-        if (++w_chunk == nchunk) {
-            w_chunk = 0;
-            w_item += gsz;
-            if (w_item < nitems) w_ct = c16_decode(p, w_item).ct;
         }
     };
     auto halo_rsrc = [&]() {
@@ -279,10 +261,10 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
         } else if (!WRES) {
             const int pi = 8 * (q - C16_HPIECES) + wave;             // 0 .. 39: the slab has 36 pieces, piece 36 carries the biases
             if (pi < C16_W_SLOTS / 64) {
-                const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((w_ct * nchunk + w_chunk) * (C16_W_SLOTS * 16) + pi * 1024);
+                const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((fi.ct * nchunk + f_chunk) * (C16_W_SLOTS * 16) + pi * 1024);
                 dma16_buf(wrs, lane * 16, soff, reinterpret_cast<float *>(img + C16_HALO_SLOTS * 16 + pi * 1024));
-            } else if (pi == C16_W_SLOTS / 64 && w_chunk == 0) {
-                dma16_buf(brs, lane < 16 ? lane * 16 : ADN_DMA_OOB, (unsigned)__builtin_amdgcn_readfirstlane(w_ct * 256),
+            } else if (pi == C16_W_SLOTS / 64 && f_chunk == 0) {
+                dma16_buf(brs, lane < 16 ? lane * 16 : ADN_DMA_OOB, (unsigned)__builtin_amdgcn_readfirstlane(fi.ct * 256),
                           reinterpret_cast<float *>(img + BIAS_OFF));
             }
         }
@@ -321,7 +303,6 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
 #pragma unroll
     for (int q = 0; q < NPIECE; ++q) fetch_piece(q, 0);
     fetch_advance();
-    if constexpr (!WRES && !FIRST) w_advance();
 
     // ---- compute side ----
     int c_item = first, c_chunk = 0, c_k = 0;
@@ -363,7 +344,8 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
             }
         }
         if (c_chunk == 0) {
-            // folded-BN bias rides in the accumulators (the copies staged it in LDS): no bias load or add in the epilogue
+            // folded-BN bias rides in the accumulators (the copies staged it in LDS): no bias load or add in the epilogue.  (As the C
+            // operand of the item's first MFMAs instead of these copies: + 46 VGPRs under hipcc 7.2, spills in the FIRST form.)
             const char *bl = (WRES ? smem16 : img) + BIAS_OFF + g * 16;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -413,6 +395,9 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
 #ifdef ADN_EXPERIMENTS
             if (tp == 8 && tl_on) tl_c = __builtin_amdgcn_s_memtime();
 #endif
+            // fetch bookkeeping (next chunk / next item: decode + the halo plan) once the last copy is out, between MFMA groups
+            // instead of in the tail of the step, where both waves of a SIMD would do it with the matrix pipe idle
+            if (tp == (NPIECE - 1) / PPT + 1 && more) fetch_advance();
             if (!(abl & 1)) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -420,10 +405,6 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
                     for (int j = 0; j < 4; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tp & 1][j], xr[dx & 1][i + dy], acc[i][j], 0, 0, 0);
             }
-        }
-        if (more) {
-            fetch_advance();
-            if constexpr (!WRES && !FIRST) w_advance();
         }
 
         if (++c_chunk == nchunk) {
@@ -457,7 +438,7 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
                     float v = part[i];
                     v += __shfl_xor(v, 16, 64);
                     v += __shfl_xor(v, 32, 64);
-                    const unsigned off = (g == 0 && gyb + i < p.H && gx < p.W && !(abl & 4)) ? (unsigned)(((gyb + i) * p.W + gx) * 4) : ADN_DMA_OOB;
+                    const unsigned off = ((g == 0) & (gyb + i < p.H) & (gx < p.W) & !(abl & 4)) ? (unsigned)(((gyb + i) * p.W + gx) * 4) : ADN_DMA_OOB;
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v + p.dot_bias), yrs, off, 0, 0);
                 }
             } else {
@@ -471,7 +452,7 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
                 unsigned ooff[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    ooff[i] = (gyb + i < p.H && gx < p.W && !(abl & 4)) ? (unsigned)(((gyb + i) * p.W + gx) * 32 + g * 8) : ADN_DMA_OOB;
+                    ooff[i] = ((gyb + i < p.H) & (gx < p.W) & !(abl & 4)) ? (unsigned)(((gyb + i) * p.W + gx) * 32 + g * 8) : ADN_DMA_OOB;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const unsigned cb = (unsigned)__builtin_amdgcn_readfirstlane((ci.ct * 4 + j) * (int)HWb);
@@ -499,7 +480,7 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
                                 m[d] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(t, __builtin_bit_cast(f16x2, ou)));
                             }
                             const int py = (gyb >> 1) + a, px = gx >> 1;
-                            const unsigned poff = (!(l16 & 1) && py < Hp && px < Wp && !(abl & 4)) ? (unsigned)((py * Wp + px) * 32 + g * 8) : ADN_DMA_OOB;
+                            const unsigned poff = (!(l16 & 1) & (py < Hp) & (px < Wp) & !(abl & 4)) ? (unsigned)((py * Wp + px) * 32 + g * 8) : ADN_DMA_OOB;
                             __builtin_amdgcn_raw_buffer_store_b64(m, prs, poff, cbp, 0);
                         }
                     }
@@ -507,7 +488,7 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
             }
             c_item += gsz;
             ++c_k;
-            if (c_item < nitems) ci = c16_decode(p, c_item);
+            ci = fi;                                   // (the fetch side moved on to this item one step ago: nchunk >= 2)
             // this wave's copies of the next step have landed; its NST stores (younger than every copy) may still be in flight
             constexpr int NST = EPI == CONV3X3_RELU_DOT ? 4 : EPI == CONV3X3_RELU_POOL ? 24 : 16;
             // (s_barrier as inline asm: __syncthreads() carries a fence that hipcc lowers to s_waitcnt vmcnt(0) -- it would wait
@@ -560,11 +541,7 @@ hipError_t launch_c16(const ConvArgs &a, hipStream_t st)
     a2.nct = a.Cout / 64;
     const long nitems = (long)a.N * a2.tilesY * a2.tilesX * a2.nct;
     long maxd = a2.nct > a2.tilesX ? (a2.nct > a2.tilesY ? a2.nct : a2.tilesY) : (a2.tilesX > a2.tilesY ? a2.tilesX : a2.tilesY);
-    {
-        static const int order = []() { const char *e = std::getenv("ADN_C16_ORDER"); return e ? std::atoi(e) : 0; }();
-        a2.pair = (order && a2.nct > 1) ? 1 : 0;   // item order: 1 = cout tile slowest (c16_decode); measured 5-8 % slower on the deep layers
-    }
-    if (a2.pair && nitems / a2.nct > maxd) maxd = nitems / a2.nct;
+    a2.pair = 0;
     if (nitems <= 0 || nitems > 0x7fffffffL || (unsigned long long)nitems * (unsigned long long)maxd >= 0x100000000ull) return hipErrorInvalidValue;
     a2.fdGc = make_fastdiv((unsigned)a2.nct);
     a2.fdNcg = make_fastdiv((unsigned)(nitems / a2.nct));
