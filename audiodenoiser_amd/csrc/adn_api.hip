@@ -119,8 +119,8 @@ struct adn_unet {
     // differs in the last bits (both within 1e-4 of the reference).  ADN_BATCH_INVARIANT=1 when the handle is created pins one
     // kernel per layer by geometry alone: a clip's result is bit-identical whatever batch it is computed in.
     // fp16 path, 3x3 layers: 0 = conv_dma<_Float16> (32x32x16 MFMA, rounds 1-3) everywhere, 1 = conv16_f16 (16x16x32 MFMA,
-    // persistent, LDS-resident weights for the 64 -> 64 layers) wherever it applies, 2 = per layer (ADN_F16_CONV=32 / 16 / unset)
-    int f16_conv = 2;
+    // persistent, LDS-resident weights for the 64 -> 64 layers) wherever it applies = the default (ADN_F16_CONV=32 / 16)
+    int f16_conv = 1;
     bool f16_fuse_first = true;    // ADN_F16_FIRST=0: Conv2d(1 -> 64) as its own launch (conv_first_kernel) on the fp16 path (A/B runs)
     bool batch_invariant = false;
     // thresholds of the rule, in F(4x4,3x3) workgroups of the launch, calibrated on per-launch timings at batch 1-16
@@ -458,18 +458,12 @@ Algo choose_algo(const adn_unet *h, adn::ConvKind kind, const adn::ConvArgs &a)
     return r;
 }
 
-// fp16 path: which 3x3 layers run conv16_f16.  Per-layer rule of the default mode: measured per launch at batch 256
-// (profiles/r04_f16_kernels.txt)
+// fp16 path: which 3x3 layers run conv16_f16: every layer it applies to (all but the two with a single input or output plane).
+// Measured per launch at batch 256 and as whole forwards at batch 1 / 4 / 16 (profiles/r04_f16_kernels.txt,
+// r04_f16_small_batch.txt): ahead of conv_dma<_Float16> on every layer since the bookkeeping of a step moved out of its tail.
 bool f16_use_conv16(const adn_unet *h, adn::ConvKind kind, const adn::ConvArgs &a16)
 {
-    if (h->f16_conv == 0 || !adn::conv16_applicable(kind, a16)) return false;
-    if (h->f16_conv == 1) return true;
-    // per layer (profiles/r04_f16_kernels.txt): the seven layers fed by at most 128 channels (513x256 and 256x128 levels) are
-    // 4-25 % faster on conv16_f16 (few chunks per item: its cheap epilogue and resident weights count); from 256 input channels
-    // on the two families are within +-4 %, conv_dma's two workgroups per CU slightly ahead
-    const int cin = a16.s0.C + a16.s1.C;
-    (void)kind;
-    return cin <= 128;
+    return h->f16_conv != 0 && adn::conv16_applicable(kind, a16);
 }
 
 hipError_t launch_conv3(const adn_unet *h, adn::ConvKind kind, const adn::ConvArgs &a, float *partial, hipStream_t st)
@@ -771,7 +765,7 @@ int adn_unet_create_general(adn_unet **handle, int device, const float *const *t
     if (const char *cs = std::getenv("ADN_CONVT_SPLIT")) h->convt_split = std::atoi(cs) != 0;
     if (const char *bi = std::getenv("ADN_BATCH_INVARIANT")) h->batch_invariant = std::atoi(bi) != 0;
     if (const char *ff = std::getenv("ADN_F16_FIRST")) h->f16_fuse_first = std::atoi(ff) != 0;
-    if (const char *fc = std::getenv("ADN_F16_CONV")) h->f16_conv = std::atoi(fc) == 32 ? 0 : std::atoi(fc) == 16 ? 1 : 2;
+    if (const char *fc = std::getenv("ADN_F16_CONV")) h->f16_conv = std::atoi(fc) == 32 ? 0 : 1;
     if (const char *ag = std::getenv("ADN_AUTO_GRID")) h->auto_grid = std::atol(ag);      // tuning knobs of the small-grid rule
     if (const char *ag = std::getenv("ADN_AUTO_GRID64")) h->auto_grid64 = std::atol(ag);
     if (h->f16) h->convt_split = false;
