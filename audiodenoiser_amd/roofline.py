@@ -54,7 +54,7 @@ def executed_mfma_flops(launch: dict, algo: str, wino_mode: str = "auto") -> flo
     ``winograd_tile`` says so; wino_conv_dma_f32 =
     F(2x2,3x3), 16 multiply-adds per 2x2 tile = 8 FLOP per padded pixel on 16x16 tiles, elsewhere), "direct"
     (conv_mfma<float>: TH x 16 tiles with TH = 16 for the 64-channel layers and 8 otherwise, 18 FLOP per pixel) or
-    "direct_f16" (conv_dma<_Float16>: 32 x 16 tiles for every layer).  Transposed convolutions run
+    "direct_f16" (conv16_f16 / conv_dma<_Float16>: 32 x 16 tiles for every layer).  Transposed convolutions run
     conv_dma<T, 8, 128, ...>: K = Cin, 4*Cout GEMM columns, 8 x 16 tiles of input pixels.  The first (Cin = 1) and
     last (1x1, Cout = 1) layers do not use the matrix cores: 0."""
     kind = launch["kind"]

@@ -43,7 +43,7 @@ Sub-benchmarks in the same JSON line (rank 0, N = 1 only; --no-extras skips them
           stft_wave_kernel (algorithmic bytes = audio read once + magnitudes written once = 1 590 084 B per clip),
           with the C oracle's STFT timed beside it.
   `f16`   BASELINE configs[4]: the same forward at batch 256 with fp16 storage + fp16 MFMA; MFMA roofline of
-          conv_dma<_Float16> against the dense fp16 peak.
+          conv16_f16 against the dense fp16 peak.
 
 cpu_baseline: the oracle's torch.nn.functional restatement of the reference forward (same ATen/oneDNN kernels
 the reference's model.py dispatches to; kind "port") timed on this host's cores on a bounded sample.
@@ -362,8 +362,8 @@ def bench_f16(sd_np, dev, batch=256, steps=10, warmup=2):
            "steps": steps, "warmup": warmup, "dtype": "f16", "ms_per_step": round(el / steps * 1e3, 3),
            "frames_per_s": round(batch * T_FRAMES * steps / el, 1),
            "roofline": conv_roofline(ms_mean, batch, "direct_f16", PEAK_MFMA_F16_TFLOPS,
-                                     "conv_dma<_Float16, 32, 64, ...> (LDS-DMA staged direct implicit GEMM, v_mfma_f32_32x32x16_f16; 14 layers) + conv16_f16 "
-                                     "(v_mfma_f32_16x16x32_f16, persistent, LDS-resident weights / fused first layer; the 3 layers fed by 64 channels)", "conv_mfma_f16"),
+                                     "conv16_f16 (LDS-DMA staged direct implicit GEMM on v_mfma_f32_16x16x32_f16, one persistent workgroup per CU; LDS-resident "
+                                     "weights for the 64 -> 64 layers, first layer fused into down1's second conv): all 17 3x3 layers", "conv_mfma_f16"),
            "forward": forward_summary(ms_mean, batch, "direct_f16", PEAK_MFMA_F16_TFLOPS)}
     net._release()
     del net, x, target
@@ -462,7 +462,7 @@ def kernel_names(f16: bool):
     algo = "direct_f16" if f16 else ("direct" if direct else "winograd")
     peak = PEAK_MFMA_F16_TFLOPS if f16 else PEAK_MFMA_F32_TFLOPS
     wmode = wino_tile_mode()
-    kname = ("conv_dma<_Float16, 32, 64, ...> + conv16_f16 (LDS-DMA staged direct implicit GEMM, fp16 MFMA)" if f16 else
+    kname = ("conv16_f16 (LDS-DMA staged direct implicit GEMM, fp16 MFMA v_mfma_f32_16x16x32_f16)" if f16 else
              "conv_mfma<float> (direct implicit GEMM, fp32 MFMA)" if direct else
              "wino_conv_dma_f32 (Winograd F(2x2,3x3), fp32 MFMA v_mfma_f32_16x16x4_f32)" if wmode == "2" else
              "wino4_conv_f32 (Winograd F(4x4,3x3), fp32 MFMA v_mfma_f32_16x16x4_f32)")
