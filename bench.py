@@ -365,6 +365,18 @@ def bench_f16(sd_np, dev, batch=256, steps=10, warmup=2):
                                      "conv16_f16 (LDS-DMA staged direct implicit GEMM on v_mfma_f32_16x16x32_f16, one persistent workgroup per CU; LDS-resident "
                                      "weights for the 64 -> 64 layers, first layer fused into down1's second conv): all 17 3x3 layers", "conv_mfma_f16"),
            "forward": forward_summary(ms_mean, batch, "direct_f16", PEAK_MFMA_F16_TFLOPS)}
+    # one clip through the same handle (forward only, back-to-back calls, HIP events): configs[0]'s shape on the fp16 path
+    x1 = x[:1].contiguous()
+    with torch.no_grad():
+        for _ in range(5):
+            net(x1)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            net(x1)
+        e1.record()
+        torch.cuda.synchronize(dev)
+    res["b1_ms_per_forward"] = round(e0.elapsed_time(e1) / 50, 4)
     net._release()
     del net, x, target
     torch.cuda.empty_cache()
