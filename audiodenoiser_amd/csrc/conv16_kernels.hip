@@ -168,9 +168,9 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
             for (int e = 0; e < 8; ++e) {
                 const int t = (g & 1) ? 8 : e;
                 const float wv = p.firstw[t * 64 + 16 * jj + l16];
-                w1f[jj][e] = ((g & 1) && e > 0) ? (_Float16)0.f : (_Float16)wv;
+                w1f[jj][e] = ((g & 1) && e > 0) ? (_Float16)0.f : (_Float16)(0.5f * wv);       // HALF the weight and bias (exact):
             }
-            b1[jj] = *reinterpret_cast<const f32x4 *>(p.firstb + 16 * jj + 4 * g);
+            b1[jj] = *reinterpret_cast<const f32x4 *>(p.firstb + 16 * jj + 4 * g) * 0.5f;           // ReLU below is h + |h|
         }
     }
     auto win_issue = [&](const C16Item &it) {       // loads of item `it`'s window into registers (out of range = zero padding)
@@ -200,39 +200,54 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
     // halo block m (16 pixels) of chunk FC (0 / 1) of the fetch item, into image `buf`: gather the 3x3 windows of its pixels from the
     // fp16 planes, two MFMAs (16 channels each), bias + ReLU, zero outside the image (the layer's own zero padding), 8-byte LDS writes
     // block m = 8 q + wave of piece q: its lanes' halo pixel is fixed for the whole kernel
-    int fb_rowpx[FIRST ? 5 : 1];                    // row | px << 8 | valid << 16
+    // (block 38 has 4 halo pixels and 12 lanes beyond them: those run on like the others -- their window reads stay inside the
+    // plane's reserved bytes, their results land in the pad slots behind the block's 1 224 used ones, which nobody reads)
+    int fb_rowpx[FIRST ? 5 : 1];                    // row | px << 8
+    static_assert(C16_HALO_MB * 16 * 2 <= C16_BLK_SLOTS && ((C16_HALO_MB * 16 - 1) / C16_PW + 2) * C16_WIN_COLS + C16_PW + 2 <= C16_WIN_PLANE / 2,
+                  "overhanging lanes of the last halo block");
     if constexpr (FIRST) {
 #pragma unroll
         for (int q = 0; q < 5; ++q) {
-            int hp = 16 * (8 * q + wave) + l16;
-            const int valid = hp < C16_HALO_PX ? 1 : 0;
-            hp = valid ? hp : C16_HALO_PX - 1;
+            const int hp = 16 * (8 * q + wave) + l16;
             const int row = hp / C16_PW;
-            fb_rowpx[q] = row | ((hp - row * C16_PW) << 8) | (valid << 16);
+            fb_rowpx[q] = row | ((hp - row * C16_PW) << 8);
+            asm volatile("" : "+v"(fb_rowpx[q]));       // (kept in a register: hipcc otherwise redoes the division for every block)
         }
+        // 96 zero bytes behind the first plane's 720 halfs: what the odd k groups read for elements 1-7 of their fragment
+        if (tid < 24) *reinterpret_cast<unsigned *>(smem16 + WIN_OFF + C16_WIN_N * 2 + tid * 4) = 0u;
     }
     auto first_block = [&](int q, int buf, auto fc_tag) {
         constexpr int FC = decltype(fc_tag)::value;
         const int row = fb_rowpx[FIRST ? q : 0] & 0xff, px = (fb_rowpx[FIRST ? q : 0] >> 8) & 0xff;
-        const bool valid = (fb_rowpx[FIRST ? q : 0] >> 16) & 1;
-        const _Float16 *wp = reinterpret_cast<const _Float16 *>(smem16 + WIN_OFF + (f_k & 1) * C16_WIN_BYTES + (g >= 2 ? C16_WIN_PLANE : 0)) +
-                             row * C16_WIN_COLS + px;
-        _Float16 t[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) t[k] = wp[(k / 3) * C16_WIN_COLS + (k % 3)];
-        const _Float16 z = (_Float16)0.f;
+        // byte offset in LDS of the pixel's 3x3 window in the plane of this k group (g >= 2: the remainder plane)
+        const int wo = WIN_OFF + (f_k & 1) * C16_WIN_BYTES + (g >= 2 ? C16_WIN_PLANE : 0) + (row * C16_WIN_COLS + px) * 2;
+        // even k groups: taps 0-7 of the window; odd ones: tap 8, then zeros -- two base offsets instead of eight selects
         const bool odd = g & 1;
-        const f16x8 xf = {odd ? t[8] : t[0], odd ? z : t[1], odd ? z : t[2], odd ? z : t[3], odd ? z : t[4], odd ? z : t[5], odd ? z : t[6], odd ? z : t[7]};
+        typedef const __attribute__((address_space(3))) _Float16 *lds_h;
+        const unsigned lbase = (unsigned)reinterpret_cast<size_t>((__attribute__((address_space(3))) char *)smem16);   // LDS address of the array
+        const unsigned o0 = lbase + (odd ? wo + (2 * C16_WIN_COLS + 2) * 2 : wo);
+        unsigned o1 = lbase + (odd ? WIN_OFF + C16_WIN_N * 2 : wo);
+        // (the offset goes through an empty asm before every read: hipcc otherwise merges neighbouring halfs into 4- and 8-byte
+        // LDS reads at 2-byte alignment, which the hardware serves far slower than separate 2-byte reads -- 3.77 vs 2.89 ms
+        // for the layer)
+        f16x8 xf;
+        xf[0] = *(lds_h)(size_t)o0;
+#pragma unroll
+        for (int k = 1; k < 8; ++k) {
+            asm volatile("" : "+v"(o1));
+            xf[k] = *(lds_h)(size_t)(o1 + ((k / 3) * C16_WIN_COLS + (k % 3)) * 2);
+        }
         const int gy = fi.ty * C16_TH - 1 + row, gx = fi.tx * C16_TW - 1 + px;
         const bool inside = ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W);
         char *dst = img_base + buf * IMG_B + row * C16_ROWB + px * 32 + g * 8;
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb) {
             const f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1f[2 * FC + jb], xf, b1[2 * FC + jb], 0, 0, 0);
-            f16x4 hv;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) hv[r] = inside ? (_Float16)relu_keep_nan(a[r]) : z;
-            if (valid) *reinterpret_cast<f16x4 *>(dst + jb * (C16_BLK_SLOTS * 16)) = hv;
+            // (a = y / 2: h + |h| = max(y, 0) keeping NaN; zero outside the image = this layer's own zero padding)
+            const f16x2 h0 = {(_Float16)(a[0] + __builtin_fabsf(a[0])), (_Float16)(a[1] + __builtin_fabsf(a[1]))};
+            const f16x2 h1 = {(_Float16)(a[2] + __builtin_fabsf(a[2])), (_Float16)(a[3] + __builtin_fabsf(a[3]))};
+            const u32x2 hv = {inside ? __builtin_bit_cast(unsigned, h0) : 0u, inside ? __builtin_bit_cast(unsigned, h1) : 0u};
+            *reinterpret_cast<u32x2 *>(dst + jb * (C16_BLK_SLOTS * 16)) = hv;
         }
     };
     auto halo_rsrc = [&]() {
@@ -476,7 +491,7 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
                                 const unsigned r0 = hv[2 * a][d], r1 = hv[2 * a + 1][d];
                                 const f16x2 t = __builtin_elementwise_max(__builtin_bit_cast(f16x2, r0), __builtin_bit_cast(f16x2, r1));
                                 const unsigned tu = __builtin_bit_cast(unsigned, t);
-                                const unsigned ou = (unsigned)__shfl_xor((int)tu, 1, 64);
+                                const unsigned ou = (unsigned)__builtin_amdgcn_mov_dpp((int)tu, 0xB1, 0xf, 0xf, true);      // quad_perm [1,0,3,2]: the neighbouring pixel's value
                                 m[d] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(t, __builtin_bit_cast(f16x2, ou)));
                             }
                             const int py = (gyb >> 1) + a, px = gx >> 1;
