@@ -349,7 +349,13 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
         const int buf = PAR;
         const bool more = s + 1 < nsteps;
         const char *img = img_base + buf * IMG_B;
-        const char *wimg = WRES ? smem16 + c_chunk * (C16_W_SLOTS * 16) : img + C16_HALO_SLOTS * 16;
+        // WRES: an item is exactly two steps (Cin = 64), so the chunk IS the parity of the step.  CT: first / last chunk taken as
+        // compile-time facts -- the epilogue exists in the odd step only, and the even one starts its accumulators from the bias as
+        // the C operand of its first MFMAs instead of 64 copies.  Costs 14 VGPRs under hipcc 7.2 (the FIRST form, at 225, would
+        // spill: it keeps the run-time form, as does the streamed one, where the C-operand form costs 46).
+        constexpr bool CT = WRES && !FIRST;
+        const bool first_chunk = CT ? PAR == 0 : c_chunk == 0;
+        const char *wimg = WRES ? smem16 + (CT ? PAR : c_chunk) * (C16_W_SLOTS * 16) : img + C16_HALO_SLOTS * 16;
         bool win_pending = false;
         if constexpr (FIRST) {
             // first step of an item: the NEXT item's window starts its trip (its first halo is computed in the next step)
@@ -358,15 +364,17 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
                 win_pending = true;
             }
         }
-        if (c_chunk == 0) {
-            // folded-BN bias rides in the accumulators (the copies staged it in LDS): no bias load or add in the epilogue.  (As the C
-            // operand of the item's first MFMAs instead of these copies: + 46 VGPRs under hipcc 7.2, spills in the FIRST form.)
+        // folded-BN bias rides in the accumulators (the copies staged it in LDS): no bias load or add in the epilogue
+        f32x4 biasv[4];
+        if (first_chunk) {
             const char *bl = (WRES ? smem16 : img) + BIAS_OFF + g * 16;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const f32x4 b = *reinterpret_cast<const f32x4 *>(bl + j * 64);
+                biasv[j] = *reinterpret_cast<const f32x4 *>(bl + j * 64);
+                if constexpr (!CT) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i][j] = b;
+                    for (int i = 0; i < 4; ++i) acc[i][j] = biasv[j];
+                }
             }
         }
         // Fragment reads.  The X fragment of (row block i, tap (dy, dx)) is halo row 4 wave + i + dy at column offset dx: for one
@@ -418,11 +426,15 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tp & 1][j], xr[dx & 1][i + dy], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tp & 1][j], xr[dx & 1][i + dy],
+                                                                           (CT && PAR == 0 && tp == 0) ? biasv[j] : acc[i][j], 0, 0, 0);
             }
         }
 
-        if (++c_chunk == nchunk) {
+        bool last_chunk;
+        if constexpr (CT) last_chunk = PAR == 1;
+        else last_chunk = ++c_chunk == nchunk;
+        if (last_chunk) {
             // ---- epilogue of the item: ReLU, 8-byte stores straight from the accumulators, through buffer descriptors (a lane
             // outside the image stores out of range = nowhere): no branches, a fixed number of stores, so the wait below can
             // leave exactly them in flight ----
@@ -623,7 +635,7 @@ bool conv16_applicable(ConvKind kind, const ConvArgs &a)
 {
     if (kind != CONV3X3_RELU && kind != CONV3X3_RELU_POOL && kind != CONV3X3_RELU_DOT) return false;
     if (a.firstw) return kind == CONV3X3_RELU_POOL && a.firstb && a.s0.C == 1 && a.s1.C == 0 && a.Cout == 64;   // fused first layer
-    if ((a.s0.C & 31) || (a.s1.C & 31) || (a.Cout & 63)) return false;
+    if ((a.s0.C & 31) || (a.s1.C & 31) || (a.Cout & 63) || a.s0.C + a.s1.C < 64) return false;     // (>= 2 chunks: the compute side trails the fetch side by one step)
     if (kind == CONV3X3_RELU_DOT && (a.Cout != 64 || !a.dotw || !a.dot_out)) return false;
     return true;
 }
@@ -631,7 +643,7 @@ bool conv16_applicable(ConvKind kind, const ConvArgs &a)
 hipError_t launch_conv16(ConvKind kind, const ConvArgs &a, bool resident, hipStream_t st)
 {
     if (!conv16_applicable(kind, a)) return hipErrorInvalidValue;
-    if (resident && (a.nchunk > 2 || a.Cout != 64)) return hipErrorInvalidValue;
+    if (resident && (a.nchunk != 2 || a.Cout != 64)) return hipErrorInvalidValue;      // (WRES: chunk = parity of the step)
     if (a.firstw) return (resident && a.nchunk == 2) ? launch_c16<CONV3X3_RELU_POOL, true, true>(a, st) : hipErrorInvalidValue;
     if (resident) {
         if (kind == CONV3X3_RELU_DOT) return launch_c16<CONV3X3_RELU_DOT, true>(a, st);
