@@ -192,7 +192,9 @@ def build_variant(name: str, defines, experiments: bool = True) -> str:
     """Cross-compile a build-time VARIANT of the library (extra -D switches, by default with the experiment switches
     compiled in) to ``_lib/variants/libadn_<name>.so`` without touching the production library.  Variant sweeps are
     compiled in the build container and shipped to the GPU box with the tree; a process picks one with
-    ``ADN_LIBADN_PATH`` (see ``_lib.load``).  Tools only: nothing in the product path sets that variable."""
+    ``ADN_LIBADN_PATH`` (see ``_lib.load``).  Tools only: nothing in the product path sets that variable.
+    NOTE for A/B runs: an experiments variant is 2-3 % slower than the production library built from the same source (the
+    ablation switches are run-time tests inside the kernels) -- compare variants with variants, or pass ``--production``."""
     hipcc = hipcc_path()
     if hipcc is None:
         raise RuntimeError("hipcc not found")

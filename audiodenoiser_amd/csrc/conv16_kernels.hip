@@ -64,7 +64,8 @@ constexpr int C16_HALO_MB = (C16_HALO_PX + 15) / 16;
 template <bool WRES, bool FIRST = false> struct C16Lds {
     static constexpr int IMG_SLOTS = WRES ? C16_HALO_SLOTS : C16_HALO_SLOTS + C16_W_SLOTS + C16_B_SLOTS;
     static constexpr int RES_SLOTS = WRES ? 2 * C16_W_SLOTS + C16_B_SLOTS : 0;   // resident: weights of two chunks (Cin = 64) + biases
-    static constexpr size_t BYTES = (size_t)(RES_SLOTS + 2 * IMG_SLOTS) * 16 + (FIRST ? 2 * C16_WIN_BYTES : 0);
+    static constexpr int SINK_OFF = (RES_SLOTS + 2 * IMG_SLOTS) * 16;        // streamed form: 1 KB where the copies of nothing land
+    static constexpr size_t BYTES = (size_t)SINK_OFF + (FIRST ? 2 * C16_WIN_BYTES : 0) + (WRES ? 0 : 1024);
     static_assert(BYTES <= 160 * 1024, "LDS budget");
 };
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -256,10 +257,17 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
         const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(hb >> 32));
         return dma_rsrc(reinterpret_cast<const void *>(((unsigned long long)hi << 32) | lo), (unsigned)__builtin_amdgcn_readfirstlane((int)himg_bytes));
     };
-    auto halo_soff = [&](int q) {
-        const int blk = 8 * q + wave >= 20 ? 1 : 0;
+    // scalar offsets of the fetch step, recomputed when the fetch state moves (fetch_scalars): halo block 0 of the chunk inside
+    // its source, and the chunk's weight slab
+    unsigned hsoff0 = 0, wsoff = 0;
+    auto fetch_scalars = [&]() {
         const int cl = f_chunk < p.nchunk0 ? f_chunk : f_chunk - p.nchunk0;          // chunk inside the current source
-        return (unsigned)__builtin_amdgcn_readfirstlane((2 * cl + blk) * (int)hblk_bytes);
+        hsoff0 = (unsigned)__builtin_amdgcn_readfirstlane(2 * cl * (int)hblk_bytes);
+        wsoff = (unsigned)__builtin_amdgcn_readfirstlane((fi.ct * nchunk + f_chunk) * (C16_W_SLOTS * 16));
+    };
+    auto halo_soff = [&](int q) {                   // pieces 0, 1: block 0; 3, 4: block 1; piece 2: waves 0-3 block 0, 4-7 block 1
+        const unsigned h1 = hsoff0 + (unsigned)__builtin_amdgcn_readfirstlane((int)hblk_bytes);
+        return q < 2 ? hsoff0 : q > 2 ? h1 : (wave < 4 ? hsoff0 : h1);
     };
     // piece q (0 .. NPIECE-1) of the fetch step into image `buf`
     auto fetch_piece = [&](int q, int buf) {
@@ -274,13 +282,21 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
             // when it runs short of SGPRs, and a descriptor in VGPRs makes every copy a waterfall loop)
             dma16_buf(halo_rsrc(), hcur[q], halo_soff(q), reinterpret_cast<float *>(img + (8 * q + wave) * 1024));
         } else if (!WRES) {
-            const int pi = 8 * (q - C16_HPIECES) + wave;             // 0 .. 39: the slab has 36 pieces, piece 36 carries the biases
-            if (pi < C16_W_SLOTS / 64) {
-                const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((fi.ct * nchunk + f_chunk) * (C16_W_SLOTS * 16) + pi * 1024);
-                dma16_buf(wrs, lane * 16, soff, reinterpret_cast<float *>(img + C16_HALO_SLOTS * 16 + pi * 1024));
-            } else if (pi == C16_W_SLOTS / 64 && f_chunk == 0) {
-                dma16_buf(brs, lane < 16 ? lane * 16 : ADN_DMA_OOB, (unsigned)__builtin_amdgcn_readfirstlane(fi.ct * 256),
-                          reinterpret_cast<float *>(img + BIAS_OFF));
+            // the slab has 36 pieces, piece 36 carries the biases: pieces 0-31 go out unconditionally (4 rounds of 8 waves); in
+            // the fifth round waves 0-3 copy pieces 32-35, wave 4 the biases (first chunk of an item), and the others -- instead
+            // of branching around a copy, which costs the wave two taken branches between MFMA groups -- copy nothing (offset
+            // out of range) into a sink
+            const int k = q - C16_HPIECES;
+            const int pi = 8 * k + wave;
+            float *sink = reinterpret_cast<float *>(smem16 + L::SINK_OFF);
+            if (k < 4) {
+                dma16_buf(wrs, lane * 16, wsoff + (unsigned)(pi * 1024), reinterpret_cast<float *>(img + C16_HALO_SLOTS * 16 + pi * 1024));
+            } else {
+                const bool isw = wave < 4, isb = (wave == 4) & (f_chunk == 0);
+                dma16_buf(wrs, isw ? lane * 16 : ADN_DMA_OOB, wsoff + (unsigned)(pi * 1024),
+                          isw ? reinterpret_cast<float *>(img + C16_HALO_SLOTS * 16 + pi * 1024) : sink);
+                dma16_buf(brs, (isb && lane < 16) ? lane * 16 : ADN_DMA_OOB, (unsigned)__builtin_amdgcn_readfirstlane(fi.ct * 256),
+                          isb ? reinterpret_cast<float *>(img + BIAS_OFF) : sink);
             }
         }
     };
@@ -296,6 +312,7 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
         } else if (f_chunk == p.nchunk0) {
             if constexpr (!FIRST) plan(p.s1, fi);   // virtual concat: the second source (with its pad offset)
         }
+        if constexpr (!FIRST) fetch_scalars();
     };
     constexpr int PPT = FIRST ? 1 : C16_PPT;       // pieces per tap (the computed halo blocks are heavier than a copy: one per tap)
     constexpr int NPIECE = FIRST ? (C16_HALO_MB + 7) / 8 : C16_HPIECES + (WRES ? 0 : C16_WPIECES);
@@ -315,6 +332,7 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    if constexpr (!FIRST) fetch_scalars();
 #pragma unroll
     for (int q = 0; q < NPIECE; ++q) fetch_piece(q, 0);
     fetch_advance();
