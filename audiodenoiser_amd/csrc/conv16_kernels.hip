@@ -270,7 +270,8 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
         return q < 2 ? hsoff0 : q > 2 ? h1 : (wave < 4 ? hsoff0 : h1);
     };
     // piece q (0 .. NPIECE-1) of the fetch step into image `buf`
-    auto fetch_piece = [&](int q, int buf) {
+    // (`kill`: 0, or ADN_DMA_OOB in the last step of the workgroup -- its copies then fetch nothing: no branch around them)
+    auto fetch_piece = [&](int q, int buf, unsigned kill = 0u) {
         char *img = img_base + buf * IMG_B;
         if constexpr (FIRST) {
             if (8 * q + wave < C16_HALO_MB) {                            // 39 blocks over 8 waves x 5 pieces
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
         } else if (q < C16_HPIECES) {
             // (descriptor words through readfirstlane, halo_rsrc: they are wave-uniform, but hipcc keeps loop-carried scalars in VGPRs
             // when it runs short of SGPRs, and a descriptor in VGPRs makes every copy a waterfall loop)
-            dma16_buf(halo_rsrc(), hcur[q], halo_soff(q), reinterpret_cast<float *>(img + (8 * q + wave) * 1024));
+            dma16_buf(halo_rsrc(), hcur[q] | kill, halo_soff(q), reinterpret_cast<float *>(img + (8 * q + wave) * 1024));
         } else if (!WRES) {
             // the slab has 36 pieces, piece 36 carries the biases: pieces 0-31 go out unconditionally (4 rounds of 8 waves); in
             // the fifth round waves 0-3 copy pieces 32-35, wave 4 the biases (first chunk of an item), and the others -- instead
@@ -290,12 +291,12 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
             const int pi = 8 * k + wave;
             float *sink = reinterpret_cast<float *>(smem16 + L::SINK_OFF);
             if (k < 4) {
-                dma16_buf(wrs, lane * 16, wsoff + (unsigned)(pi * 1024), reinterpret_cast<float *>(img + C16_HALO_SLOTS * 16 + pi * 1024));
+                dma16_buf(wrs, (unsigned)(lane * 16) | kill, wsoff + (unsigned)(pi * 1024), reinterpret_cast<float *>(img + C16_HALO_SLOTS * 16 + pi * 1024));
             } else {
                 const bool isw = wave < 4, isb = (wave == 4) & (f_chunk == 0);
-                dma16_buf(wrs, isw ? lane * 16 : ADN_DMA_OOB, wsoff + (unsigned)(pi * 1024),
+                dma16_buf(wrs, (isw ? (unsigned)(lane * 16) : ADN_DMA_OOB) | kill, wsoff + (unsigned)(pi * 1024),
                           isw ? reinterpret_cast<float *>(img + C16_HALO_SLOTS * 16 + pi * 1024) : sink);
-                dma16_buf(brs, (isb && lane < 16) ? lane * 16 : ADN_DMA_OOB, (unsigned)__builtin_amdgcn_readfirstlane(fi.ct * 256),
+                dma16_buf(brs, ((isb && lane < 16) ? (unsigned)(lane * 16) : ADN_DMA_OOB) | kill, (unsigned)__builtin_amdgcn_readfirstlane(fi.ct * 256),
                           isb ? reinterpret_cast<float *>(img + BIAS_OFF) : sink);
             }
         }
@@ -362,17 +363,20 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
     unsigned long long tl_c = 0, tl_sum[3] = {0, 0, 0}, tl_0 = tl_on ? __builtin_amdgcn_s_memtime() : 0, tl_first = tl_0;
 #endif
     // one step = one 32-channel chunk of one item; PAR = parity of the step = the LDS image it computes from
-    auto step = [&](auto par_tag, const int s) __attribute__((always_inline)) {
+    // ROLE of the step inside its item: 1 = first chunk, 2 = a middle one, 3 = the last, 0 = decided at run time (c_chunk)
+    auto step = [&](auto par_tag, auto role_tag, const int s) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par_tag)::value;
+        constexpr int ROLE = decltype(role_tag)::value;
         const int buf = PAR;
         const bool more = s + 1 < nsteps;
+        const unsigned kill = more ? 0u : ADN_DMA_OOB;       // last step: the copies run on and fetch nothing
         const char *img = img_base + buf * IMG_B;
-        // WRES: an item is exactly two steps (Cin = 64), so the chunk IS the parity of the step.  CT: first / last chunk taken as
-        // compile-time facts -- the epilogue exists in the odd step only, and the even one starts its accumulators from the bias as
-        // the C operand of its first MFMAs instead of 64 copies.  Costs 14 VGPRs under hipcc 7.2 (the FIRST form, at 225, would
-        // spill: it keeps the run-time form, as does the streamed one, where the C-operand form costs 46).
-        constexpr bool CT = WRES && !FIRST;
-        const bool first_chunk = CT ? PAR == 0 : c_chunk == 0;
+        // CT: the step's place in its item is a compile-time fact (ROLE; an item is an even number of steps, so parities are
+        // fixed too): the epilogue exists in the last step only -- where hipcc then weaves it into the trailing MFMAs -- and the
+        // first one starts its accumulators from the bias as the C operand of its first MFMAs instead of 64 copies.  The FIRST
+        // form, at 225 VGPRs, would spill that way: it keeps the run-time form (ROLE 0).
+        constexpr bool CT = ROLE != 0;
+        const bool first_chunk = CT ? ROLE == 1 : c_chunk == 0;
         const char *wimg = WRES ? smem16 + (CT ? PAR : c_chunk) * (C16_W_SLOTS * 16) : img + C16_HALO_SLOTS * 16;
         bool win_pending = false;
         if constexpr (FIRST) {
@@ -428,10 +432,10 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
             }
             // the next step's copies go out between the first taps' MFMA groups (PPT per tap): the last one has the rest of
             // the step to land before the wait at its end
-            if (more && !(abl & 2)) {
+            if ((!FIRST || more) && !(abl & 2)) {          // (FIRST: the "pieces" are computed halo blocks -- skipped, not killed)
 #pragma unroll
                 for (int q = tp * PPT; q < (tp + 1) * PPT; ++q)
-                    if (q < NPIECE) fetch_piece(q, buf ^ 1);
+                    if (q < NPIECE) fetch_piece(q, buf ^ 1, kill);
             }
 #ifdef ADN_EXPERIMENTS
             if (tp == 8 && tl_on) tl_c = __builtin_amdgcn_s_memtime();
@@ -445,12 +449,12 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tp & 1][j], xr[dx & 1][i + dy],
-                                                                           (CT && PAR == 0 && tp == 0) ? biasv[j] : acc[i][j], 0, 0, 0);
+                                                                           (ROLE == 1 && tp == 0) ? biasv[j] : acc[i][j], 0, 0, 0);
             }
         }
 
         bool last_chunk;
-        if constexpr (CT) last_chunk = PAR == 1;
+        if constexpr (CT) last_chunk = ROLE == 3;
         else last_chunk = ++c_chunk == nchunk;
         if (last_chunk) {
             // ---- epilogue of the item: ReLU, 8-byte stores straight from the accumulators, through buffer descriptors (a lane
@@ -563,10 +567,26 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
         }
 #endif
     };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    if constexpr (FIRST) {
 #pragma clang loop unroll(disable)
-    for (int s = 0; s < nsteps; s += 2) {
-        step(std::integral_constant<int, 0>{}, s);
-        if (s + 1 < nsteps) step(std::integral_constant<int, 1>{}, s + 1);
+        for (int s = 0; s < nsteps; s += 2) {
+            step(I0{}, I0{}, s);
+            step(I1{}, I0{}, s + 1);
+        }
+    } else {
+        // items of nchunk steps (even: launch_conv16): first | middle pairs | last
+#pragma clang loop unroll(disable)
+        for (int s = 0; s < nsteps;) {
+            step(I0{}, std::integral_constant<int, 1>{}, s++);
+#pragma clang loop unroll(disable)
+            for (int c = 2; c < nchunk; c += 2) {
+                step(I1{}, std::integral_constant<int, 2>{}, s++);
+                step(I0{}, std::integral_constant<int, 2>{}, s++);
+            }
+            step(I1{}, std::integral_constant<int, 3>{}, s++);
+        }
     }
 #ifdef ADN_EXPERIMENTS
     if (tl_on && lane == 0) {
@@ -653,7 +673,8 @@ bool conv16_applicable(ConvKind kind, const ConvArgs &a)
 {
     if (kind != CONV3X3_RELU && kind != CONV3X3_RELU_POOL && kind != CONV3X3_RELU_DOT) return false;
     if (a.firstw) return kind == CONV3X3_RELU_POOL && a.firstb && a.s0.C == 1 && a.s1.C == 0 && a.Cout == 64;   // fused first layer
-    if ((a.s0.C & 31) || (a.s1.C & 31) || (a.Cout & 63) || a.s0.C + a.s1.C < 64) return false;     // (>= 2 chunks: the compute side trails the fetch side by one step)
+    // (an even number of chunks, at least two: the compute side trails the fetch side by one step, and a step's parity fixes its LDS image)
+    if ((a.s0.C & 31) || (a.s1.C & 31) || (a.Cout & 63) || ((a.s0.C + a.s1.C) & 63) || a.s0.C + a.s1.C < 64) return false;
     if (kind == CONV3X3_RELU_DOT && (a.Cout != 64 || !a.dotw || !a.dot_out)) return false;
     return true;
 }
