@@ -159,8 +159,10 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
     const __amdgpu_buffer_rsrc_t brs = dma_rsrc(p.bias, (unsigned)p.Cout * 4u);
     // ---- FIRST: operands of the first convolution and the input window ----
     int f_k = 0;                                    // ordinal of the fetch item among this workgroup's items (window buffer = f_k & 1)
-    f16x8 w1f[4];                                   // W fragment of cout block jj: lane (cout % 16, k group g): g even = taps 0-7, g odd = tap 8
-    f32x4 b1[4];                                    // folded-BN bias of couts 16 jj + 4 g .. + 3 (the accumulator's starting value)
+    // W fragment of cout block jj: lane (cout % 16, k group g): g even = taps 0-7, g odd = tap 8, then the folded-BN bias (its
+    // fp16 leading part in group 1, the remainder in group 3: the X fragments carry 1.0 there), then zeros -- K = 32 has room
+    // for it, and the MFMAs start from C = 0 instead of 16 bias registers
+    f16x8 w1f[4];
     float wl[2] = {0.f, 0.f};                       // window values of the NEXT item in flight (elements tid, tid + 512)
     if constexpr (FIRST) {
 #pragma unroll
@@ -170,8 +172,12 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
                 const int t = (g & 1) ? 8 : e;
                 const float wv = p.firstw[t * 64 + 16 * jj + l16];
                 w1f[jj][e] = ((g & 1) && e > 0) ? (_Float16)0.f : (_Float16)(0.5f * wv);       // HALF the weight and bias (exact):
+            }                                                                                    // ReLU below is h + |h|
+            if (g & 1) {
+                const float hb = 0.5f * p.firstb[16 * jj + l16];
+                const _Float16 bh = (_Float16)hb;
+                w1f[jj][1] = g == 1 ? bh : (_Float16)(hb - (float)bh);
             }
-            b1[jj] = *reinterpret_cast<const f32x4 *>(p.firstb + 16 * jj + 4 * g) * 0.5f;           // ReLU below is h + |h|
         }
     }
     auto win_issue = [&](const C16Item &it) {       // loads of item `it`'s window into registers (out of range = zero padding)
@@ -214,8 +220,9 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
             fb_rowpx[q] = row | ((hp - row * C16_PW) << 8);
             asm volatile("" : "+v"(fb_rowpx[q]));       // (kept in a register: hipcc otherwise redoes the division for every block)
         }
-        // 96 zero bytes behind the first plane's 720 halfs: what the odd k groups read for elements 1-7 of their fragment
-        if (tid < 24) *reinterpret_cast<unsigned *>(smem16 + WIN_OFF + C16_WIN_N * 2 + tid * 4) = 0u;
+        // 96 bytes behind the first plane's 720 halfs: what the odd k groups read for elements 1-7 of their fragment -- 1.0 for
+        // element 1 (byte offset 2: the bias slot), zeros for the rest
+        if (tid < 24) *reinterpret_cast<unsigned *>(smem16 + WIN_OFF + C16_WIN_N * 2 + tid * 4) = tid == 0 ? 0x3C000000u : 0u;
     }
     auto first_block = [&](int q, int buf, auto fc_tag) {
         constexpr int FC = decltype(fc_tag)::value;
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
         char *dst = img_base + buf * IMG_B + row * C16_ROWB + px * 32 + g * 8;
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb) {
-            const f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1f[2 * FC + jb], xf, b1[2 * FC + jb], 0, 0, 0);
+            const f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1f[2 * FC + jb], xf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
             // (a = y / 2: h + |h| = max(y, 0) keeping NaN; zero outside the image = this layer's own zero padding)
             const f16x2 h0 = {(_Float16)(a[0] + __builtin_fabsf(a[0])), (_Float16)(a[1] + __builtin_fabsf(a[1]))};
             const f16x2 h1 = {(_Float16)(a[2] + __builtin_fabsf(a[2])), (_Float16)(a[3] + __builtin_fabsf(a[3]))};
@@ -381,7 +388,7 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
         bool win_pending = false;
         if constexpr (FIRST) {
             // first step of an item: the NEXT item's window starts its trip (its first halo is computed in the next step)
-            if (c_chunk == 0 && c_item + gsz < nitems) {
+            if (first_chunk && c_item + gsz < nitems) {
                 win_issue(c16_decode(p, c_item + gsz));
                 win_pending = true;
             }
@@ -572,8 +579,8 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
     if constexpr (FIRST) {
 #pragma clang loop unroll(disable)
         for (int s = 0; s < nsteps; s += 2) {
-            step(I0{}, I0{}, s);
-            step(I1{}, I0{}, s + 1);
+            step(I0{}, std::integral_constant<int, 1>{}, s);
+            step(I1{}, std::integral_constant<int, 3>{}, s + 1);
         }
     } else {
         // items of nchunk steps (even: launch_conv16): first | middle pairs | last
