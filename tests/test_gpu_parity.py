@@ -680,23 +680,28 @@ def test_convt_split_bf16_matches_exact_fp32_form(dev, weights_np, golden_dir, m
 
 
 # ---------------------------------------------------------------------------------------------- fp16 path
-@pytest.mark.parametrize("conv", ["default", "16", "32"])
+@pytest.mark.parametrize("conv", ["default", "first0", "32"])
 def test_fp16_path_within_1e2_of_fp32_reference(dev, weights_np, golden_dir, conv, monkeypatch):
     """BASELINE configs[4]: fp16 storage + fp16 MFMA (fp32 accumulate); outputs within 1e-2 (relative to max|ref|)
     of the fp32 reference goldens, on every golden shape, and block outputs within 1e-2 of their rms.  Both 3x3 kernel
-    families: conv16_f16 (16x16x32 MFMA, ADN_F16_CONV=16 forces it wherever it applies), conv_dma<_Float16> (32x32x16,
-    ADN_F16_CONV=32) and the per-layer default."""
+    families: conv16_f16 (16x16x32 MFMA; the default, with Conv2d(1 -> 64) computed inside down1's second conv, and with
+    ADN_F16_FIRST=0 as its own launch: down1's second conv then runs the resident-weight pooling form) and
+    conv_dma<_Float16> (32x32x16, ADN_F16_CONV=32)."""
     from audiodenoiser_amd.model import UNet
     from audiodenoiser_amd.weights import make_input
     monkeypatch.delenv("ADN_F16_CONV", raising=False)
-    if conv != "default":
+    monkeypatch.delenv("ADN_F16_FIRST", raising=False)
+    if conv == "32":
         monkeypatch.setenv("ADN_F16_CONV", conv)
+    elif conv == "first0":
+        monkeypatch.setenv("ADN_F16_FIRST", "0")
     m = UNet(1, 1)
     m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in weights_np.items()}, strict=True)
     m = m.to(dev).eval().set_compute_dtype("f16")
     with torch.no_grad():
         m(torch.zeros((1, 1, 16, 16), device=dev))               # the handle (and its switches) is created at the first forward
     monkeypatch.delenv("ADN_F16_CONV", raising=False)
+    monkeypatch.delenv("ADN_F16_FIRST", raising=False)
     for (n, f, t) in GOLDEN_SHAPES + ((3, 20, 36), (2, 31, 16)):
         if (f, t) not in [(s[1], s[2]) for s in GOLDEN_SHAPES]:
             import oracle
