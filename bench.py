@@ -335,7 +335,7 @@ def bench_stft(dev, clips=10000, length=132300, n_fft=1024, hop=256, steps=20, w
     return res
 
 
-def bench_f16(sd_np, dev, batch=256, steps=10, warmup=2):
+def bench_f16(sd_np, dev, batch=256, steps=10, warmup=2, single_clip=True):
     """BASELINE configs[4] on one GPU: fp16 storage + fp16 MFMA forward at batch 256 (+ per-clip loss, as the main step)."""
     from audiodenoiser_amd import _lib
     from audiodenoiser_amd.loss import perceptual_loss_per_clip
@@ -366,7 +366,13 @@ def bench_f16(sd_np, dev, batch=256, steps=10, warmup=2):
                                      "weights for the 64 -> 64 layers, first layer fused into down1's second conv): all 17 3x3 layers", "conv_mfma_f16"),
            "forward": forward_summary(ms_mean, batch, "direct_f16", PEAK_MFMA_F16_TFLOPS)}
     # one clip through the same handle (forward only, back-to-back calls, HIP events): configs[0]'s shape on the fp16 path
+    # (--no-f16-b1 under the profiler: 55 single-clip forwards would dominate the per-family means of the PMC passes)
     x1 = x[:1].contiguous()
+    if not single_clip:
+        net._release()
+        del net, x, target
+        torch.cuda.empty_cache()
+        return res
     with torch.no_grad():
         for _ in range(5):
             net(x1)
@@ -691,6 +697,7 @@ def main() -> None:
                          "kernel statistics of the headline kernel are not mixed with other batch sizes)")
     ap.add_argument("--stft-steps", type=int, default=20)
     ap.add_argument("--f16-steps", type=int, default=10)
+    ap.add_argument("--no-f16-b1", action="store_true", help="skip the single-clip timing inside the f16 extra (profiler runs)")
     ap.add_argument("--b256-steps", type=int, default=10)
     ap.add_argument("--no-stft-cpu", action="store_true", help="skip the C-oracle STFT timing inside the stft sub-benchmark")
     ap.add_argument("--no-finite-check", action="store_true",
@@ -770,7 +777,7 @@ def main() -> None:
                 out["stft"] = bench_stft(dev, steps=args.stft_steps, cpu_clips=0 if args.no_stft_cpu else 4096)
             if not f16:
                 if "f16" in extras:
-                    out["f16"] = bench_f16(sd_np, dev, steps=args.f16_steps)
+                    out["f16"] = bench_f16(sd_np, dev, steps=args.f16_steps, single_clip=not args.no_f16_b1)
                 if "fp32_b256" in extras:
                     out["fp32_b256"] = bench_fp32_b256(sd_np, dev, steps=args.b256_steps)
                 if "b1" in extras:
