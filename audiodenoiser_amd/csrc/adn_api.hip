@@ -76,7 +76,6 @@ struct Conv3x3Layer {
     size_t w_off, b_off;   // float offsets into the packed device buffer
     size_t w4_off;         // F(4x4,3x3) pack of the same weights (fp32 Winograd path), 0 = none
     size_t w16_off;        // fp16 path: pack_conv16 form of the same weights (16x16x32 kernel), 0 = none
-    size_t b16_off;        // ... and HALF the folded bias (see pack_conv16)
 };
 struct ConvTLayer {
     int Cin, Cout;
@@ -174,9 +173,7 @@ void pack_conv3x3(const float *w /*(Cout,Cin,3,3)*/, const std::vector<float> &s
 
 // fp16 weights for conv16_f16 (conv16_kernels.hip): [cout tile of 64][chunk of 32 channels][tap][cout block j of 16][k group g]
 // [cout % 16][8 halfs], input channel = chunk*32 + 8g + e: the W fragment of (tap, j) is 64 lanes x 16 bytes = 1 KB contiguous,
-// lane = 16 g + cout % 16.  BatchNorm scale folded.  Weights (and the layer's bias, b16_off) are packed at HALF their value --
-// exact: a power of two -- so that the kernel's accumulators hold y / 2 and its ReLU is the single NaN-keeping operation
-// h + |h| = max(y, 0).
+// lane = 16 g + cout % 16.  BatchNorm scale folded.
 void pack_conv16(const float *w /*(Cout,Cin,3,3)*/, const std::vector<float> &scale, int Cin, int Cout, _Float16 *dst)
 {
     const int nchunk = Cin / 32;
@@ -185,7 +182,7 @@ void pack_conv16(const float *w /*(Cout,Cin,3,3)*/, const std::vector<float> &sc
             const int ct = co / 64, j = (co % 64) / 16, c16 = co % 16, ch = ci / 32, g = (ci % 32) / 8, e = ci % 8;
             for (int tap = 0; tap < 9; ++tap)
                 dst[(((((size_t)ct * nchunk + ch) * 9 + tap) * 4 + j) * 64 + g * 16 + c16) * 8 + e] =
-                    (_Float16)(0.5f * (w[((size_t)co * Cin + ci) * 9 + tap] * scale[co]));
+                    (_Float16)(w[((size_t)co * Cin + ci) * 9 + tap] * scale[co]);
         }
 }
 
@@ -395,7 +392,6 @@ adn::ConvArgs conv_args(const adn_unet *h, const Conv3x3Layer &L, adn::ConvKind 
     a.wpk = h->dev + L.w_off;
     a.wpk4 = (h->use_wino && h->use_wino4 && L.w4_off) ? h->dev + L.w4_off : (h->f16 && L.w16_off) ? h->dev + L.w16_off : nullptr;
     a.bias = h->dev + L.b_off;
-    a.bias16 = L.b16_off ? h->dev + L.b16_off : nullptr;
     a.out = out;
     a.pool = pool;
     a.N = N;
@@ -468,10 +464,9 @@ bool f16_use_conv16(const adn_unet *h, adn::ConvKind kind, const adn::ConvArgs &
 
 hipError_t launch_conv3(const adn_unet *h, adn::ConvKind kind, const adn::ConvArgs &a, float *partial, hipStream_t st)
 {
-    if (h->f16 && a.wpk4 && a.bias16) {                  // wpk4 carries the pack_conv16 form on the fp16 path
+    if (h->f16 && a.wpk4) {                              // wpk4 carries the pack_conv16 form on the fp16 path
         adn::ConvArgs a16 = a;
         a16.wpk = a.wpk4;
-        a16.bias = a.bias16;
         a16.nchunk0 = a.s0.C / 32;
         a16.nchunk = (a.s0.C + a.s1.C) / 32;
         if (a.firstw) {                                  // fused first layer: the 64 input channels are computed inside the kernel
@@ -596,7 +591,6 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
         t.wpk = h->dev + TL.w_off;
         t.wpk4 = nullptr;
         t.bias = h->dev + TL.b_off;
-        t.bias16 = nullptr;
         t.out = Y;
         t.pool = nullptr;
         t.N = N;
@@ -811,11 +805,6 @@ int adn_unet_create_general(adn_unet **handle, int device, const float *const *t
         }
         L.b_off = reserve(Cout);
         std::memcpy(host.data() + L.b_off, bias.data(), sizeof(float) * Cout);
-        L.b16_off = 0;
-        if (L.w16_off) {
-            L.b16_off = reserve(Cout);
-            for (int c = 0; c < Cout; ++c) host[L.b16_off + c] = 0.5f * bias[c];
-        }
         ti += 6;
     };
     // downconv1: first conv has Cin = 1 -> direct kernel, weights [tap][cout]

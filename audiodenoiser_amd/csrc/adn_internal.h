@@ -41,11 +41,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t dma_rsrc(const void *base, uns
 #endif
 
 #ifdef __HIPCC__
-// ReLU that keeps a NaN a NaN (fmaxf / v_max_f32 is IEEE maxNum: it returns the other operand): the fp16 path and the direct
-// kernels use it so that an overflow of fp16 storage (inf, then inf - inf) reaches the output as a non-finite value instead of
-// being clamped to a plausible-looking zero.  (The fp32 Winograd kernels keep v_max_f32 in their tuned epilogues: their contract is
-// finite inputs)
-__device__ __forceinline__ float relu_keep_nan(float v) { return v < 0.f ? 0.f : v; }
+// ReLU and max-pool as the reference computes them (torch.relu / nn.MaxPool2d, /root/reference/code/model.py:13,16,26): a NaN
+// operand gives NaN, -inf gives 0, +inf stays +inf -- IEEE-754-2019 `maximum`, ONE instruction on gfx950 (v_maximum3_f32;
+// v_pk_maximum3_f16 for packed halfs).  fmaxf / v_max_f32 is maxNum: it returns the other operand, i.e. it would turn the NaN
+// that an inf pixel of the reference's own loader (data_loader.py:41-42: fp16 overflow) becomes into a plausible-looking zero.
+// Every ReLU and pooling maximum of the library goes through these.
+__device__ __forceinline__ float relu_nan(float v) { return __builtin_elementwise_maximum(v, 0.f); }
+__device__ __forceinline__ float max_nan(float a, float b) { return __builtin_elementwise_maximum(a, b); }
+__device__ __forceinline__ float max4_nan(float a, float b, float c, float d) { return max_nan(max_nan(a, b), max_nan(c, d)); }
 #endif
 
 // One activation source of a convolution (fp32 or fp16 storage, decided by the launcher).  (offY, offX) is
@@ -74,7 +77,6 @@ struct ConvArgs {
     const void *wpk;       // packed weights, see pack_* in adn_api.hip
     const void *wpk4;      // fp32 3x3 layers: the same weights packed for the F(4x4,3x3) kernel (pack_wino4_3x3), or nullptr
     const float *bias;     // per GEMM column (BatchNorm folded), always fp32
-    const float *bias16;   // fp16 path, conv16_f16 only: half the bias (pack_conv16 in adn_api.hip), or nullptr
     void *out;             // output in the blocked layout (above)
     void *pool;            // optional 2x2 max-pooled output, same layout (CONV3X3_RELU_POOL)
     int N, H, W;           // tile domain: output H,W for 3x3; INPUT h,w for the transposed convolution

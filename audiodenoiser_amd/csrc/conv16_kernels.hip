@@ -171,10 +171,10 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
             for (int e = 0; e < 8; ++e) {
                 const int t = (g & 1) ? 8 : e;
                 const float wv = p.firstw[t * 64 + 16 * jj + l16];
-                w1f[jj][e] = ((g & 1) && e > 0) ? (_Float16)0.f : (_Float16)(0.5f * wv);       // HALF the weight and bias (exact):
-            }                                                                                    // ReLU below is h + |h|
+                w1f[jj][e] = ((g & 1) && e > 0) ? (_Float16)0.f : (_Float16)wv;
+            }
             if (g & 1) {
-                const float hb = 0.5f * p.firstb[16 * jj + l16];
+                const float hb = p.firstb[16 * jj + l16];
                 const _Float16 bh = (_Float16)hb;
                 w1f[jj][1] = g == 1 ? bh : (_Float16)(hb - (float)bh);
             }
@@ -251,9 +251,9 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb) {
             const f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1f[2 * FC + jb], xf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            // (a = y / 2: h + |h| = max(y, 0) keeping NaN; zero outside the image = this layer's own zero padding)
-            const f16x2 h0 = {(_Float16)(a[0] + __builtin_fabsf(a[0])), (_Float16)(a[1] + __builtin_fabsf(a[1]))};
-            const f16x2 h1 = {(_Float16)(a[2] + __builtin_fabsf(a[2])), (_Float16)(a[3] + __builtin_fabsf(a[3]))};
+            // (ReLU keeping NaN: relu_nan, adn_internal.h; zero outside the image = this layer's own zero padding)
+            const f16x2 h0 = {(_Float16)relu_nan(a[0]), (_Float16)relu_nan(a[1])};
+            const f16x2 h1 = {(_Float16)relu_nan(a[2]), (_Float16)relu_nan(a[3])};
             const u32x2 hv = {inside ? __builtin_bit_cast(unsigned, h0) : 0u, inside ? __builtin_bit_cast(unsigned, h1) : 0u};
             *reinterpret_cast<u32x2 *>(dst + jb * (C16_BLK_SLOTS * 16)) = hv;
         }
@@ -470,10 +470,9 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
             c_chunk = 0;
             const int gx = ci.tx * C16_TW + l16;
             const int gyb = ci.ty * C16_TH + wave * 4;
-            // ReLU in ONE vector operation that keeps NaN and +inf: the host packs HALF the weights and biases (pack_conv16: exact
-            // in binary floating point), so the accumulators hold y / 2 and y/2 + |y/2| = max(y, 0); v_max_f32 would turn a NaN
-            // into 0 (IEEE maxNum) and an overflow of fp16 storage upstream (inf, then inf - inf) into plausible-looking values.
-            auto relu2 = [](float h) { return h + __builtin_fabsf(h); };
+            // ReLU as torch.relu computes it (relu_nan, adn_internal.h: one v_maximum3_f32): NaN stays NaN, +inf stays +inf, -inf
+            // becomes 0 -- an overflow of fp16 storage upstream (inf, then inf - inf) reaches the output as a non-finite value.
+            auto relu2 = [](float h) { return relu_nan(h); };
             auto relu_pk = [&](float a, float b) {
                 const f16x2 h = {(_Float16)relu2(a), (_Float16)relu2(b)};
                 return __builtin_bit_cast(unsigned, h);
@@ -520,8 +519,8 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
                     }
                     if constexpr (EPI == CONV3X3_RELU_POOL) {
                         // MaxPool2d(2), floor mode, on the packed halfs (rounding is monotonic: the maximum of the rounded values is the
-                        // rounded maximum; the values are >= 0 or NaN -- a NaN is dropped HERE (v_pk_max_f16), it stays in the skip
-                        // tensor): rows (2a, 2a+1) are this lane's row blocks, columns (2x, 2x+1) neighbouring lanes
+                        // rounded maximum; v_pk_maximum3_f16: a NaN in the window gives NaN, as nn.MaxPool2d does): rows (2a, 2a+1) are
+                        // this lane's row blocks, columns (2x, 2x+1) neighbouring lanes
                         const unsigned cbp = (unsigned)__builtin_amdgcn_readfirstlane((ci.ct * 4 + j) * (int)HWpb);
 #pragma unroll
                         for (int a = 0; a < 2; ++a) {
@@ -530,10 +529,10 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
                             for (int d = 0; d < 2; ++d) {
                                 // (vector elements through named temporaries: __builtin_bit_cast of `vec[d]` itself reads element 0 whatever d is)
                                 const unsigned r0 = hv[2 * a][d], r1 = hv[2 * a + 1][d];
-                                const f16x2 t = __builtin_elementwise_max(__builtin_bit_cast(f16x2, r0), __builtin_bit_cast(f16x2, r1));
+                                const f16x2 t = __builtin_elementwise_maximum(__builtin_bit_cast(f16x2, r0), __builtin_bit_cast(f16x2, r1));
                                 const unsigned tu = __builtin_bit_cast(unsigned, t);
                                 const unsigned ou = (unsigned)__builtin_amdgcn_mov_dpp((int)tu, 0xB1, 0xf, 0xf, true);      // quad_perm [1,0,3,2]: the neighbouring pixel's value
-                                m[d] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(t, __builtin_bit_cast(f16x2, ou)));
+                                m[d] = __builtin_bit_cast(unsigned, __builtin_elementwise_maximum(t, __builtin_bit_cast(f16x2, ou)));
                             }
                             const int py = (gyb >> 1) + a, px = gx >> 1;
                             const unsigned poff = (!(l16 & 1) & (py < Hp) & (px < Wp) & !(abl & 4)) ? (unsigned)((py * Wp + px) * 32 + g * 8) : ADN_DMA_OOB;
@@ -548,8 +547,9 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
             // this wave's copies of the next step have landed; its NST stores (younger than every copy) may still be in flight
             constexpr int NST = EPI == CONV3X3_RELU_DOT ? 4 : EPI == CONV3X3_RELU_POOL ? 24 : 16;
             // (s_barrier as inline asm: __syncthreads() carries a fence that hipcc lowers to s_waitcnt vmcnt(0) -- it would wait
-            // for the stores.  Every LDS read of this step has been consumed by an MFMA, and the copies into the other image were
-            // awaited just above, so the bare barrier orders everything the next step relies on.)
+            // for the stores.  Every LDS read of this step has been consumed by an MFMA, the copies into the other image were
+            // awaited just above and the FIRST form's LDS writes (win_write) are drained explicitly below, so the bare barrier
+            // orders everything the next step relies on.)
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (NST == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else if constexpr (NST == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
@@ -558,7 +558,12 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         if constexpr (FIRST) {
-            if (win_pending) win_write((c_k + 1) & 1);     // (the loads are older than this step's stores: the compiler's wait leaves those in flight)
+            if (win_pending) {
+                win_write((c_k + 1) & 1);                  // (the loads are older than this step's stores: the compiler's wait leaves those in flight)
+                // the window's ds_write_b16s must have landed before the bare s_barrier below (hipcc inserts no wait in front of an
+                // inline-asm barrier, gfx9 has no implicit one): other waves read the window in the next step (first_block)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
         }
 #ifdef ADN_EXPERIMENTS
         unsigned long long tl_w = 0;

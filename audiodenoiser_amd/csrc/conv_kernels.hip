@@ -111,7 +111,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &p, f32x16 (&acc)[T
             } else {
                 float v[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = relu_keep_nan(acc[i][j][r] + bv);
+                for (int r = 0; r < 16; ++r) v[r] = relu_nan(acc[i][j][r] + bv);
                 T *ob = outp + (size_t)n * p.H * p.W * p.Cout + act_off<T>(p.Cout, (long)p.H * p.W, 0, col);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -129,8 +129,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &p, f32x16 (&acc)[T
                     for (int q = 0; q < 2; ++q)
 #pragma unroll
                         for (int pp = 0; pp < 4; pp += 2) {
-                            const float m4 = fmaxf(fmaxf(v[4 * q + pp], v[4 * q + pp + 1]),
-                                                   fmaxf(v[4 * (q + 2) + pp], v[4 * (q + 2) + pp + 1]));
+                            const float m4 = max4_nan(v[4 * q + pp], v[4 * q + pp + 1], v[4 * (q + 2) + pp], v[4 * (q + 2) + pp + 1]);
                             const int px = ((tx * TW) >> 1) + (pp >> 1) + 2 * hh + 4 * q;
                             if (py < Hp && px < Wp) pb[((size_t)py * Wp + px) * ps] = (T)m4;
                         }
@@ -350,7 +349,7 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs &p, f32x16 (
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 v[r] = acc[i][j][r] + bv;
-                if (EPI != CONVT2X2) v[r] = relu_keep_nan(v[r]);
+                if (EPI != CONVT2X2) v[r] = relu_nan(v[r]);
             }
             if constexpr (sizeof(T) == 4) {
 #pragma unroll
@@ -450,11 +449,8 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvArgs &p, f32x16 (
                     const piece_t m1 = *reinterpret_cast<const piece_t *>(b0 + RS);
                     const piece_t m2 = *reinterpret_cast<const piece_t *>(b0 + TW * RS);
                     const piece_t m3 = *reinterpret_cast<const piece_t *>(b0 + TW * RS + RS);
-#pragma unroll
-                    for (int e = 0; e < EPP; ++e) {
-                        const T a = m[e] > m1[e] ? m[e] : m1[e], b = m2[e] > m3[e] ? m2[e] : m3[e];
-                        m[e] = a > b ? a : b;
-                    }
+                    // (NaN-propagating maximum, as nn.MaxPool2d: v_maximum3_f32 / v_pk_maximum3_f16)
+                    m = __builtin_elementwise_maximum(__builtin_elementwise_maximum(m, m1), __builtin_elementwise_maximum(m2, m3));
                     *reinterpret_cast<piece_t *>(poolp + (size_t)n * Hp * Wp * p.Cout +
                                                  act_off<T>(p.Cout, (long)Hp * Wp, (long)py * Wp + px, ct * BN + part * EPP)) = m;
                 }
@@ -773,7 +769,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict
             }
 #pragma unroll
             for (int k = 0; k < NV; ++k) {
-                a[k].x = fmaxf(a[k].x, 0.f); a[k].y = fmaxf(a[k].y, 0.f); a[k].z = fmaxf(a[k].z, 0.f); a[k].w = fmaxf(a[k].w, 0.f);
+                a[k].x = relu_nan(a[k].x); a[k].y = relu_nan(a[k].y); a[k].z = relu_nan(a[k].z); a[k].w = relu_nan(a[k].w);
             }
             if constexpr (sizeof(T) == 4) {
 #pragma unroll

@@ -824,7 +824,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             for (int a = 0; a < 4; ++a) {
                 const f32x4 o = *reinterpret_cast<const f32x4 *>(xr + (r * 4 + a) * 256);
 #pragma unroll
-                for (int b = 0; b < 4; ++b) yy[r][a][b] = fmaxf(yy[r][a][b] + o[b], 0.f);
+                for (int b = 0; b < 4; ++b) yy[r][a][b] = relu_nan(yy[r][a][b] + o[b]);
             }
         }
         if constexpr (EPI == CONV3X3_RELU_DOT) {
@@ -875,7 +875,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                         f32x4 m;
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            m[r] = fmaxf(fmaxf(yy[r][2 * a][2 * b], yy[r][2 * a][2 * b + 1]), fmaxf(yy[r][2 * a + 1][2 * b], yy[r][2 * a + 1][2 * b + 1]));
+                            m[r] = max4_nan(yy[r][2 * a][2 * b], yy[r][2 * a][2 * b + 1], yy[r][2 * a + 1][2 * b], yy[r][2 * a + 1][2 * b + 1]);
                         if ((ABL & 4096) && m[0] != 123.456f) continue;
                         if (INT || (clip_ok && py < Hp && (gxt >> 1) + b < Wp)) *reinterpret_cast<f32x4 *>(prow + b * 8) = m;
                     }
@@ -901,7 +901,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             for (int a = 0; a < 4; ++a) {
                 const f32x4 o = *reinterpret_cast<const f32x4 *>(xr + (r * 4 + a) * 256);
 #pragma unroll
-                for (int b = 0; b < 4; ++b) yf[r][a][b] = wdot * fmaxf(W4_BIAS_ACC ? yf[r][a][b] + o[b] : yf[r][a][b] + o[b] + bias_r, 0.f);
+                for (int b = 0; b < 4; ++b) yf[r][a][b] = wdot * relu_nan(W4_BIAS_ACC ? yf[r][a][b] + o[b] : yf[r][a][b] + o[b] + bias_r);
             }
         }
         __syncthreads();                                // every wave has read its partner's exchange block
@@ -946,8 +946,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
                 for (int bp = 0; bp < 2; ++bp) {
                     const f32x4 o = *reinterpret_cast<const f32x4 *>(xr + ((rp * 4 + a) * 2 + bp) * 256);
-                    y[a][2 * bp] = __builtin_elementwise_max(y[a][2 * bp] + f32x2{o[0], o[1]}, f32x2{0.f, 0.f});
-                    y[a][2 * bp + 1] = __builtin_elementwise_max(y[a][2 * bp + 1] + f32x2{o[2], o[3]}, f32x2{0.f, 0.f});
+                    y[a][2 * bp] = __builtin_elementwise_maximum(y[a][2 * bp] + f32x2{o[0], o[1]}, f32x2{0.f, 0.f});
+                    y[a][2 * bp + 1] = __builtin_elementwise_maximum(y[a][2 * bp + 1] + f32x2{o[2], o[3]}, f32x2{0.f, 0.f});
                 }
 #pragma unroll
                 for (int b = 0; b < 4; ++b)
@@ -967,8 +967,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
                     for (int b = 0; b < 2; ++b) {
-                        const f32x2 mx2 = __builtin_elementwise_max(__builtin_elementwise_max(y[2 * a][2 * b], y[2 * a][2 * b + 1]),
-                                                                    __builtin_elementwise_max(y[2 * a + 1][2 * b], y[2 * a + 1][2 * b + 1]));
+                        const f32x2 mx2 = __builtin_elementwise_maximum(__builtin_elementwise_maximum(y[2 * a][2 * b], y[2 * a][2 * b + 1]),
+                                                                        __builtin_elementwise_maximum(y[2 * a + 1][2 * b], y[2 * a + 1][2 * b + 1]));
 #pragma unroll
                         for (int e = 0; e < 2; ++e) {
                             const float mx = mx2[e];
@@ -993,7 +993,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 const f32x4 o = *reinterpret_cast<const f32x4 *>(xr + (r * 4 + a) * 256);
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
-                    y[a][b] = fmaxf(W4_BIAS_ACC ? y[a][b] + o[b] : y[a][b] + o[b] + bias_r, 0.f);
+                    y[a][b] = relu_nan(W4_BIAS_ACC ? y[a][b] + o[b] : y[a][b] + o[b] + bias_r);
                     if constexpr (INT) {
                         if (!(ABL & 4096) || y[a][b] == 123.456f) W4_ST(orow[a][(4 * r + b) * 8], y[a][b]);
                     } else {
@@ -1007,7 +1007,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
                     for (int b = 0; b < 2; ++b) {
-                        const float mx = fmaxf(fmaxf(y[2 * a][2 * b], y[2 * a][2 * b + 1]), fmaxf(y[2 * a + 1][2 * b], y[2 * a + 1][2 * b + 1]));
+                        const float mx = max4_nan(y[2 * a][2 * b], y[2 * a][2 * b + 1], y[2 * a + 1][2 * b], y[2 * a + 1][2 * b + 1]);
                         if constexpr (INT) {
                             if (!(ABL & 4096) || mx == 123.456f) W4_ST(prow[a][(2 * r + b) * 8], mx);
                         } else {

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
                     for (int dx = 0; dx < 3; ++dx)
                         a += *reinterpret_cast<const f32x4 *>(ww + (dy * 3 + dx) * 64) * xw[dy * XS + dx];
-                a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
+                a.x = relu_nan(a.x); a.y = relu_nan(a.y); a.z = relu_nan(a.z); a.w = relu_nan(a.w);
             }
             *reinterpret_cast<f32x4 *>(smem + buf * DBUF + (k * NT + tid) * 4) = a;
         }
@@ -448,10 +448,10 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
                     s0[x] = acc[j][4 * x + 0][r] + acc[j][4 * x + 1][r] + acc[j][4 * x + 2][r];
                     s1[x] = acc[j][4 * x + 1][r] - acc[j][4 * x + 2][r] - acc[j][4 * x + 3][r];
                 }
-                v[j][0][0] = fmaxf(s0[0] + s0[1] + s0[2] + bias_r[j], 0.f);
-                v[j][1][0] = fmaxf(s0[1] - s0[2] - s0[3] + bias_r[j], 0.f);
-                v[j][0][1] = fmaxf(s1[0] + s1[1] + s1[2] + bias_r[j], 0.f);
-                v[j][1][1] = fmaxf(s1[1] - s1[2] - s1[3] + bias_r[j], 0.f);
+                v[j][0][0] = relu_nan(s0[0] + s0[1] + s0[2] + bias_r[j]);
+                v[j][1][0] = relu_nan(s0[1] - s0[2] - s0[3] + bias_r[j]);
+                v[j][0][1] = relu_nan(s1[0] + s1[1] + s1[2] + bias_r[j]);
+                v[j][1][1] = relu_nan(s1[1] - s1[2] - s1[3] + bias_r[j]);
             }
 #pragma unroll
             for (int a = 0; a < 2; ++a)
@@ -506,8 +506,8 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
-                    const float v = fmaxf(y[a][b] + bv, 0.f);
-                    mx = fmaxf(mx, v);
+                    const float v = relu_nan(y[a][b] + bv);
+                    mx = max_nan(mx, v);
                     if (gy + a < p.H && gx + b < p.W) ob[((size_t)(gy + a) * p.W + gx + b) * 8] = v;
                 }
             if (EPI == CONV3X3_RELU_POOL) {
@@ -547,9 +547,9 @@ __global__ __launch_bounds__(256) void wino_reduce_kernel(const float *__restric
             f32x4 v = *reinterpret_cast<const f32x4 *>(partial + o);
             for (int s = 1; s < ksplit; ++s) v += *reinterpret_cast<const f32x4 *>(partial + s * split_stride + o);
             v += bv;
-            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            v.x = relu_nan(v.x); v.y = relu_nan(v.y); v.z = relu_nan(v.z); v.w = relu_nan(v.w);
             *reinterpret_cast<f32x4 *>(out + (size_t)n * img + act_off<float>(Cout, (long)H * W, (long)gy * W + gx, c4)) = v;   // C8
-            mx.x = fmaxf(mx.x, v.x); mx.y = fmaxf(mx.y, v.y); mx.z = fmaxf(mx.z, v.z); mx.w = fmaxf(mx.w, v.w);
+            mx.x = max_nan(mx.x, v.x); mx.y = max_nan(mx.y, v.y); mx.z = max_nan(mx.z, v.z); mx.w = max_nan(mx.w, v.w);
         }
     if (EPI == CONV3X3_RELU_POOL && by < H / 2 && bx < W / 2)
         *reinterpret_cast<f32x4 *>(pool + (size_t)n * (H / 2) * (W / 2) * Cout +

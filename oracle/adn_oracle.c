@@ -84,7 +84,8 @@ void adno_conv3x3(const float *x, const float *w, const float *b, float *y,
     }
 }
 
-/* BatchNorm2d in eval mode followed by ReLU, in place:  x = max(0, (x-mean)/sqrt(var+eps)*gamma+beta) */
+/* BatchNorm2d in eval mode followed by ReLU, in place:  x = max(0, (x-mean)/sqrt(var+eps)*gamma+beta); a NaN stays a NaN
+ * (torch.relu, reference model.py:13,16) */
 void adno_bn_relu(float *x, const float *gamma, const float *beta, const float *mean, const float *var,
                   int N, int C, long HW, int acc64)
 {
@@ -97,19 +98,20 @@ void adno_bn_relu(float *x, const float *gamma, const float *beta, const float *
                 const double g = gamma[c], be = beta[c], mu = mean[c];
                 for (long i = 0; i < HW; ++i) {
                     double v = ((double)p[i] - mu) * inv * g + be;
-                    p[i] = v > 0.0 ? (float)v : 0.0f;
+                    p[i] = v < 0.0 ? 0.0f : (float)v;
                 }
             } else {
                 const float inv = 1.0f / sqrtf(var[c] + ADNO_BN_EPS);
                 for (long i = 0; i < HW; ++i) {
                     float v = (p[i] - mean[c]) * inv * gamma[c] + beta[c];
-                    p[i] = v > 0.0f ? v : 0.0f;
+                    p[i] = v < 0.0f ? 0.0f : v;
                 }
             }
         }
 }
 
-/* MaxPool2d(kernel 2, stride 2), floor mode: odd trailing row/column is dropped. */
+/* MaxPool2d(kernel 2, stride 2), floor mode: odd trailing row/column is dropped; a NaN in the window gives NaN (nn.MaxPool2d,
+ * reference model.py:26). */
 void adno_maxpool2(const float *x, float *y, int N, int C, int H, int W)
 {
     const int Ho = H / 2, Wo = W / 2;
@@ -121,9 +123,9 @@ void adno_maxpool2(const float *x, float *y, int N, int C, int H, int W)
             for (int w = 0; w < Wo; ++w) {
                 const float *q = xp + (long)(2 * h) * W + 2 * w;
                 float m = q[0];
-                if (q[1] > m) m = q[1];
-                if (q[W] > m) m = q[W];
-                if (q[W + 1] > m) m = q[W + 1];
+                if (q[1] > m || q[1] != q[1]) m = q[1];
+                if (q[W] > m || q[W] != q[W]) m = q[W];
+                if (q[W + 1] > m || q[W + 1] != q[W + 1]) m = q[W + 1];
                 yp[(long)h * Wo + w] = m;
             }
     }

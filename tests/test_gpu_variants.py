@@ -98,14 +98,138 @@ def test_fp16_path_on_heavy_tailed_weights(dev, golden_dir, variant_weights):
 
 
 def test_fp16_path_reports_overflow_as_non_finite_not_garbage(dev, golden_dir, variant_weights):
-    """Under the "trained" set fp16 storage overflows; the result must say so (inf / nan), never look plausible."""
+    """Under the "trained" set the reference's own activations reach 4e9 on the x100 clip (make_golden.py prints max|tap|): fp16
+    storage overflows there, and the result must SAY so -- non-finite values, never plausible-looking numbers.  Every block
+    whose reference samples exceed fp16's range must hold non-finite values, and so must the output of that clip; the x1 clip,
+    whose activations fit, stays within the fp16 bound."""
     m = _net(variant_weights("trained"), dev, "f16")
     g = load_variant_golden(golden_dir, "trained", 33, 47)
     with torch.no_grad():
-        y = m(torch.from_numpy(variant_input(golden_dir, 33, 47)).to(dev)).cpu().numpy()
-    for clip in range(2):
-        if np.isfinite(y[clip]).all():
-            assert _rel(y[clip], g["y"][clip]) <= 1e-2, clip
+        y, taps = m(torch.from_numpy(variant_input(golden_dir, 33, 47)).to(dev), return_taps=True)
+    y = y.cpu().numpy()
+    overflowing = [k for k in taps if k != "out" and np.abs(g[f"{k}_val"]).max() > 65504.0]
+    assert overflowing, "fixture no longer overflows fp16: pick a larger input scale"
+    for k in overflowing:
+        assert not bool(torch.isfinite(taps[k]).all()), f"{k}: the reference exceeds 65504 here, fp16 storage cannot be finite"
+    first = list(taps).index(overflowing[0])
+    for k in list(taps)[first:]:                              # ... and nothing downstream of the first overflow may look clean
+        assert not bool(torch.isfinite(taps[k][1]).all()), k
+    assert not np.isfinite(y[1]).all()
+    if all(np.abs(g[f"{k}_val"]).max() < 6e4 for k in taps if k != "out") and np.isfinite(y[0]).all():
+        assert _rel(y[0], g["y"][0]) <= 1e-2
+
+
+# ---- non-finite inputs: the reference's ReLU / MaxPool2d propagate NaN (model.py:13,16,26), and its loader makes inf ------------
+# Per 3x3 layer the reference poisons the 3x3 neighbourhood of a poisoned pixel.  A Winograd kernel poisons every output tile
+# whose input patch holds it: up to 2 pixels away for F(2x2,3x3) (2x2 tiles, 4x4 patches), up to 4 for F(4x4,3x3) -- 1 / 3 pixels
+# more than the reference, at the resolution of the layer.  Two layers per level going down (levels 0-3), two in the bottleneck
+# (level 4), two per level going up: 2 * (1 + 2 + 4 + 8) * 2 + 2 * 16 = 92 level-0 pixels per extra pixel.
+NONFINITE_SHAPES = ((257, 188), (513, 256), (1100, 48))
+NONFINITE_POS = {(257, 188): (20, 20), (513, 256): (60, 40), (1100, 48): (40, 20)}
+LAYER_WEIGHT = 92
+EXTRA = {"default": 3, "batch_invariant": 3, "f2x2": 1, "f4x4_forced": 3, "direct": 0, "splitk": 3, "convt_exact": 3, "f16": 0}
+
+
+def _nonfinite_input(f, t, kind):
+    from audiodenoiser_amd.weights import make_input
+    x = make_input(7, 1, f, t).copy()
+    r, c = NONFINITE_POS[(f, t)]
+    x[0, 0, r, c] = np.float32(np.inf) if kind == "inf" else np.float32(np.nan)
+    return x
+
+
+def _unpack(bits, shape):
+    n = int(np.prod(shape))
+    return np.unpackbits(bits)[:n].reshape(shape).astype(bool)
+
+
+def _check_nonfinite(m, g, f, t, kind, extra, tol, dev, label):
+    from scipy.ndimage import maximum_filter
+    x = torch.from_numpy(_nonfinite_input(f, t, kind)).to(dev)
+    with torch.no_grad():
+        y, taps = m(x, return_taps=True)
+        y_plain = m(x)
+    ref_bad = _unpack(g[f"{kind}_mask"], (f, t))
+    allowed = maximum_filter(ref_bad.astype(np.uint8), size=2 * extra * LAYER_WEIGHT + 1, mode="constant").astype(bool) if extra else ref_bad
+    compared = 0
+    for got in (y.cpu().numpy()[0, 0], y_plain.cpu().numpy()[0, 0]):
+        bad = ~np.isfinite(got)
+        assert not (ref_bad & ~bad).any(), (label, kind, "finite where the reference is not", int((ref_bad & ~bad).sum()))
+        assert not (bad & ~allowed).any(), (label, kind, "non-finite beyond the kernel family's bound", int((bad & ~allowed).sum()))
+        ok = ~bad
+        compared = int(ok.sum())
+        scale = float(np.abs(g[f"{kind}_y"]).max())
+        err = float(np.abs(got[ok] - g[f"{kind}_y"][ok]).max()) / scale if compared else 0.0
+        assert err <= tol, (label, kind, err)
+    for name, tp in taps.items():                             # block outputs: pixel-wise superset, every level
+        hw = tuple(int(v) for v in g[f"{kind}_{name}_hw"])
+        ref_px = _unpack(g[f"{kind}_{name}_mask"], hw)
+        got_px = (~torch.isfinite(tp[0])).any(dim=0).cpu().numpy()
+        assert not (ref_px & ~got_px).any(), (label, kind, name)
+    return compared, int((~allowed).sum())
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+def test_nonfinite_pixels_travel_as_in_the_reference(dev, golden_dir, weights_np, mode, monkeypatch):
+    """One +inf / one NaN input pixel (what data_loader.py:41-42 hands the network for a magnitude above 65504) against
+    unet_nonfinite_<F>x<T>.npz = the reference's own forward: the HIP non-finite set contains the reference's, exceeds it by
+    at most the kernel family's tile rounding (EXTRA * 92 pixels, see above), and every finite output matches to 1e-4."""
+    for k in ENV_KEYS:
+        monkeypatch.delenv(k, raising=False)
+    for k, v in MODES[mode].items():
+        monkeypatch.setenv(k, v)
+    m = _net(weights_np, dev)
+    checked = 0
+    for f, t in NONFINITE_SHAPES:
+        g = np.load(os.path.join(golden_dir, f"unet_nonfinite_{f}x{t}.npz"))
+        for kind in ("inf", "nan"):
+            compared, room = _check_nonfinite(m, g, f, t, kind, EXTRA[mode], TOL, dev, mode)
+            assert compared >= room                           # everything outside the bound was finite and compared
+            checked += compared
+            print(f"nonfinite {mode} {f}x{t} {kind}: {compared} finite outputs compared ({room} guaranteed by the bound)")
+    assert checked > 0
+
+
+def test_nonfinite_pixels_fp16(dev, golden_dir, weights_np, monkeypatch):
+    for k in ENV_KEYS:
+        monkeypatch.delenv(k, raising=False)
+    for first in ("1", "0"):                                  # fused first layer (default) / conv_first_kernel as its own launch
+        monkeypatch.setenv("ADN_F16_FIRST", first)
+        m = _net(weights_np, dev, "f16")
+        for f, t in NONFINITE_SHAPES:
+            g = np.load(os.path.join(golden_dir, f"unet_nonfinite_{f}x{t}.npz"))
+            for kind in ("inf", "nan"):
+                compared, room = _check_nonfinite(m, g, f, t, kind, EXTRA["f16"], 1e-2, dev, f"f16 first={first}")
+                assert compared >= room and compared > 0
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", TOL), ("f16", 1e-2)])
+def test_nonfinite_clip_poisons_neither_its_neighbours_nor_the_next_call(dev, golden_dir, weights_np, dtype, tol, monkeypatch):
+    """A poisoned clip inside a batch (F(4x4,3x3) kernels at this grid, pair mode in the bottleneck: two clips per tile) leaves
+    the other clips bit-identical to a clean run, and the next forward through the same workspace is clean again."""
+    for k in ENV_KEYS:
+        monkeypatch.delenv(k, raising=False)
+    from audiodenoiser_amd.weights import make_input
+    m = _net(weights_np, dev, dtype)
+    f, t = 513, 256
+    clean = torch.from_numpy(make_input(7, 4, f, t)).to(dev)
+    with torch.no_grad():
+        y0 = m(clean).clone()
+        bad = clean.clone()
+        bad[1, 0, 60, 40] = float("inf")
+        bad[2, 0, 300, 100] = float("nan")
+        yb = m(bad).clone()
+        y1 = m(clean).clone()
+    assert bool(torch.isfinite(y0).all())
+    assert torch.equal(y0, y1)                                # nothing sticks in the workspace
+    assert torch.equal(yb[0], y0[0]) and torch.equal(yb[3], y0[3])
+    g = np.load(os.path.join(golden_dir, f"unet_nonfinite_{f}x{t}.npz"))
+    ref_bad = _unpack(g["inf_mask"], (f, t))
+    got = yb[1, 0].cpu().numpy()
+    assert not (ref_bad & np.isfinite(got)).any()
+    ok = np.isfinite(got)
+    assert ok.any() and float(np.abs(got[ok] - g["inf_y"][ok]).max()) <= tol * float(np.abs(g["inf_y"]).max())
+    assert not bool(torch.isfinite(yb[2]).all())
 
 
 def test_loss_torch_only_terms_match_the_references_own_loss_py(dev, golden_dir):
@@ -166,13 +290,15 @@ def test_convt_split_extreme_operands(dev, weights_np, monkeypatch):
     for a, b in ((te["up1"], ts["up1"]), (ye, ys)):
         assert bool(torch.isfinite(a).all()) and bool(torch.isfinite(b).all())
         assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max())
-    # (2) non-finite activations: no assertion beyond "it runs".  The library's ReLU is fmaxf(v, 0) (IEEE maxNum: NaN -> 0,
-    # -inf -> 0), unlike torch's NaN-propagating ReLU, so non-finite values do not travel through the network in either form --
-    # finite inputs are the contract
+    # (2) an overflow to +inf in the bottleneck travels on as non-finite values in both forms (NaN where the exact form may give
+    # inf: conv_kernels.hip, split3_bf16), through every later block to the output, as torch's ReLU / MaxPool2d would carry it
     with torch.no_grad():
-        te = exact(x * 4.0, return_taps=True)[1]
-        split(x * 4.0)
+        ye, te = exact(x * 4.0, return_taps=True)
+        ys, ts = split(x * 4.0, return_taps=True)
     assert bool(torch.isinf(te["bottleneck"]).any())
+    for name in ("up1", "up2", "up3", "up4", "out"):
+        assert not bool(torch.isfinite(te[name]).all()) and not bool(torch.isfinite(ts[name]).all()), name
+    assert not bool(torch.isfinite(ye).all()) and not bool(torch.isfinite(ys).all())
 
 
 @pytest.mark.parametrize("dtype,tol", [("f32", TOL), ("f16", 1e-2)])

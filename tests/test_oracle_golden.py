@@ -162,3 +162,32 @@ def test_torch_oracle_matches_reference_golden_two_planes_three_classes(golden_d
     assert tuple(y.shape) == (2, 3, 33, 47)
     assert np.abs(y.numpy() - g["y"]).max() <= 1e-6 * np.abs(g["y"]).max()
     _check_taps(g, {k: v.numpy() for k, v in taps.items()}, 1e-6)
+
+
+NONFINITE_POS = {(257, 188): (20, 20), (1100, 48): (40, 20)}
+
+
+def _nonfinite_input(f, t, kind):
+    x = make_input(7, 1, f, t).copy()
+    r, c = NONFINITE_POS[(f, t)]
+    x[0, 0, r, c] = np.float32(np.inf) if kind == "inf" else np.float32(np.nan)
+    return x
+
+
+@pytest.mark.parametrize("f,t", list(NONFINITE_POS))
+@pytest.mark.parametrize("kind", ["inf", "nan"])
+def test_oracles_carry_nonfinite_pixels_as_the_reference_does(golden_dir, weights_np, f, t, kind):
+    """unet_nonfinite_<F>x<T>.npz (tools/make_golden.py --only nonfinite: the reference's forward on an input with one +inf /
+    NaN pixel; nn.ReLU and nn.MaxPool2d propagate NaN, model.py:13,16,26): both oracles reproduce the non-finite set exactly
+    and the finite values outside it."""
+    g = np.load(os.path.join(golden_dir, f"unet_nonfinite_{f}x{t}.npz"))
+    ref_bad = np.unpackbits(g[f"{kind}_mask"])[: f * t].reshape(f, t).astype(bool)
+    assert ref_bad.any() and not ref_bad.all()
+    x = _nonfinite_input(f, t, kind)
+    ys = [unet_torch.unet_forward(unet_torch.to_torch_state(weights_np), torch.from_numpy(x)).numpy()[0, 0]]
+    if (f, t) == (1100, 48):                                 # the C restatement on the cheaper shape only
+        ys.append(oracle.unet_forward(weights_np, x)[0, 0])
+    for y in ys:
+        bad = ~np.isfinite(y)
+        assert np.array_equal(bad, ref_bad)
+        assert np.abs(y[~bad] - g[f"{kind}_y"][~bad]).max() <= 1e-5 * np.abs(g[f"{kind}_y"]).max()

@@ -21,6 +21,8 @@ What is frozen:
   (``audiodenoiser_amd.weights.make_state_dict_variant``: trained-like BatchNorm statistics / heavy-tailed weights) on the
   real-audio input above cropped to (F, T), two clips at scale 1 and 100.
 * ``unet_c2k3_33x47.npz`` (``--only channels``) — the reference's ``UNet(in_channels=2, num_classes=3)`` on a seeded input.
+* ``unet_nonfinite_<F>x<T>.npz`` (``--only nonfinite``) — the reference forward on a seeded input with one +inf / one NaN pixel
+  (what ``data_loader.py:41-42`` produces for a magnitude above 65504): non-finite masks + the finite values outside them.
 * ``loss_cases.npz`` (``--only loss``) — the reference's ``MultiScaleSTFTLoss`` (``code/loss.py:6-35``) and ``nn.L1Loss``
   (``loss.py:75,86``) on three seeded (B, 1, F, T) pairs.  The mel term needs torchaudio (absent): not frozen, parity unpinned.
 """
@@ -173,6 +175,66 @@ def channels_case() -> None:
     print(f"wrote {path}: y{tuple(y.shape)} mean {float(y.mean()):+.4f} std {float(y.std()):.4f}")
 
 
+# ---- non-finite inputs -------------------------------------------------------------------------------------------------
+# (F, T) -> (row, column) of the poisoned pixel: near the top-left corner, so that the rows beyond the network's receptive
+# field (185 pixels; more for the Winograd kernels, whose tiles round the poisoned set outward) stay finite and are compared.
+# 1100x48: a tall image for the F(4x4,3x3) kernel, whose bound on the poisoned set exceeds 257 / 513 rows.
+NONFINITE_CASES = {(257, 188): (20, 20), (513, 256): (60, 40), (1100, 48): (40, 20)}
+NONFINITE_KINDS = {"inf": np.float32(np.inf), "nan": np.float32(np.nan)}
+
+
+def nonfinite_input(f: int, t: int, kind: str) -> np.ndarray:
+    """Input of the non-finite goldens: ``make_input(INPUT_SEED, 1, f, t)`` with ONE pixel replaced by +inf / NaN -- what the
+    reference's own loader hands the network for a magnitude above 65504 (``data_loader.py:41-42``; loader_cases.npz [0, 0])."""
+    x = make_input(INPUT_SEED, 1, f, t).copy()
+    r, c = NONFINITE_CASES[(f, t)]
+    x[0, 0, r, c] = NONFINITE_KINDS[kind]
+    return x
+
+
+def nonfinite_cases() -> None:
+    """``unet_nonfinite_<F>x<T>.npz`` (``--only nonfinite``): the reference's ``UNet.forward`` (code/model.py:53-94; nn.ReLU :13,16
+    and nn.MaxPool2d :26 propagate NaN) on a seeded input with one +inf / one NaN pixel.  Stored per kind: the output's non-finite
+    mask (packed bits), the output with the non-finite elements set to 0, and per block output the packed mask of the pixels at
+    which ANY channel is non-finite."""
+    import model as ref_model  # reference code/model.py
+
+    torch.set_num_threads(os.cpu_count() or 1)
+    net = ref_model.UNet(in_channels=1, num_classes=1)
+    net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in make_state_dict(WEIGHT_SEED).items()}, strict=True)
+    net.eval()
+    acts = {}
+
+    def hook(name):
+        def fn(_mod, _inp, out):
+            acts[name] = (out[0] if isinstance(out, tuple) else out).detach()
+        return fn
+
+    for mod_name in REF_MODULES:
+        getattr(net, mod_name).register_forward_hook(hook(mod_name))
+    for (f, t), pos in NONFINITE_CASES.items():
+        rec = {"shape": np.array([1, f, t]), "pos": np.array(pos), "weight_seed": np.array(WEIGHT_SEED), "input_seed": np.array(INPUT_SEED)}
+        for kind in NONFINITE_KINDS:
+            with torch.no_grad():
+                y = net(torch.from_numpy(nonfinite_input(f, t, kind))).numpy()[0, 0]
+            bad = ~np.isfinite(y)
+            rec[f"{kind}_mask"] = np.packbits(bad)
+            rec[f"{kind}_y"] = np.where(bad, np.float32(0), y).astype(np.float32)
+            line = []
+            for mod_name, key in zip(REF_MODULES, TAP_KEYS):
+                a = acts[mod_name].numpy()[0]                                   # (C, h, w)
+                pm = (~np.isfinite(a)).any(axis=0)
+                rec[f"{kind}_{key}_mask"] = np.packbits(pm)
+                rec[f"{kind}_{key}_hw"] = np.array(pm.shape)
+                line.append(f"{key} {int(pm.sum())}/{pm.size}")
+            rows = np.flatnonzero(bad.any(axis=1))
+            print(f"nonfinite {f}x{t} {kind} at {pos}: {int(bad.sum())} of {bad.size} outputs non-finite (rows {rows.min()}..{rows.max()}), "
+                  f"{int(np.isnan(y).sum())} NaN; poisoned pixels per block: " + ", ".join(line))
+        path = os.path.join(GOLDEN, f"unet_nonfinite_{f}x{t}.npz")
+        np.savez_compressed(path, **rec)
+        print(f"wrote {path} ({os.path.getsize(path)} B)")
+
+
 LOSS_CASES = ((3, 40, 96), (2, 257, 188), (2, 513, 256))
 
 
@@ -219,6 +281,8 @@ def main() -> None:
         return channels_case()
     if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "variants":
         return weight_variants()
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "nonfinite":
+        return nonfinite_cases()
     import data_loader as ref_loader  # reference code/data_loader.py
     import model as ref_model  # reference code/model.py
 
@@ -285,6 +349,7 @@ def main() -> None:
     weight_variants()
     loss_cases()
     channels_case()
+    nonfinite_cases()
 
 
 if __name__ == "__main__":
