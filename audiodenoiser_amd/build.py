@@ -26,7 +26,10 @@ LIB = os.path.join(LIBDIR, "libadn.so")
 STAMP = os.path.join(LIBDIR, "libadn.sha256")
 LOCK = os.path.join(LIBDIR, ".build.lock")
 ARCH = "gfx950"
-COMMON_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+COMMON_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fvisibility=hidden", "-fvisibility-inlines-hidden"]
+# only the C ABI of include/adn.h leaves the library (ADN_API there + this version script: `adn_*` global, the rest local)
+VERSION_SCRIPT = os.path.join(CSRC, "libadn.map")
+LINK_FLAGS = ["-fPIC", "-shared", f"-Wl,--version-script={VERSION_SCRIPT}"]
 # wino4_kernels.hip: the SLP vectoriser pairs unrelated scalars of the 6x6 transform into v_pk_* operations and pays
 # for it with ~140 v_mov per K-chunk (the transform is scalar by design: one channel per lane and pass)
 FILE_FLAGS = {"wino4_kernels.hip": ["-fno-slp-vectorize"]}
@@ -93,7 +96,7 @@ def _strip_comments(text: str) -> str:
 
 
 def _digest_files():
-    return _sources() + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(INCLUDE, "adn.h")]
+    return _sources() + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(INCLUDE, "adn.h"), VERSION_SCRIPT]
 
 
 def _flags_tag() -> bytes:
@@ -171,7 +174,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 workers = max(1, min(len(_sources()), (os.cpu_count() or 2) // 2))
                 with concurrent.futures.ThreadPoolExecutor(max_workers=workers) as pool:
                     objs = list(pool.map(compile_one, _sources()))
-                cmd = [hipcc, f"--offload-arch={ARCH}", "-fPIC", "-shared", "-o", tmp] + objs
+                cmd = [hipcc, f"--offload-arch={ARCH}"] + LINK_FLAGS + ["-o", tmp] + objs
                 if verbose:
                     print(" ".join(cmd), file=sys.stderr)
                 try:
@@ -210,7 +213,7 @@ def build_variant(name: str, defines, experiments: bool = True) -> str:
             return obj
         with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, (os.cpu_count() or 2) // 2)) as pool:
             objs = list(pool.map(compile_one, _sources()))
-        subprocess.run([hipcc, f"--offload-arch={ARCH}", "-fPIC", "-shared", "-o", dst] + objs, check=True)
+        subprocess.run([hipcc, f"--offload-arch={ARCH}"] + LINK_FLAGS + ["-o", dst] + objs, check=True)
     return dst
 
 

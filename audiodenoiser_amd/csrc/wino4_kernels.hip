@@ -44,71 +44,18 @@ typedef const volatile f32x4 __attribute__((address_space(3))) lds4_cv_f32x4;
 namespace {
 
 constexpr int KC = 8;                        // input channels per chunk
-// Build-time variants (tools/wino4_variants.sh passes -D switches to an experiments build; the defaults are the measured best)
-#ifndef W4_EARLY_HALO                         // 1: the first chunk's halo pieces go out one by one as their slots are planned
-#define W4_EARLY_HALO 1
-#endif
-#ifndef W4_EPI_FAST                           // 1: tile blocks wholly inside the image store without bounds checks
-#define W4_EPI_FAST 1
-#endif
-#ifndef W4_TPIN                               // 1: the whole input transform of a pass in front of its first MFMA (below)
-#define W4_TPIN 1
-#endif
-// W4_SWAP: accumulators cout-major (MFMA operands swapped: a lane holds 4 consecutive couts of one tile instead of one cout of
-// 4 tiles): 0 = never, 1 = every variant, 2 = only the fused-1x1 variant.  Measured per batch-64 step (profiles/r03_wino4_variants.txt):
-// the fused-1x1 layer gains 3.3 % (a lane adds its 4 couts in registers: 16 instead of 64 LDS writes in the dot), the plain and
-// pooling variants LOSE 2-4 % with the 16-byte stores this layout allows (same K loop instruction mix; tools/ubench/
-// mfma_operands.hip shows no operand-order effect in the MFMAs themselves) -> 2.
-#ifndef W4_SWAP
-#define W4_SWAP 2
-#endif
-// W4_PERSIST: 1 = one workgroup per CU walks its XCD's share of the logical workgroup ids (tile after tile, nothing overlapped:
-// the next tile's index arithmetic and first copies start behind the current tile's last store) instead of one workgroup per
-// tile: removes the gap between workgroups on a CU (1500-3300 clocks), the kernel-argument loads and the launch skew of the 8
-// waves (~2000 clocks at the first barrier) from every tile but the first (profiles/r02_wino4_timeline.txt).  Parity-green, but
-// measured 2.3 % SLOWER per batch-64 step (35.03 vs 34.23 ms, profiles/r03_wino4_variants.txt): inside the tile loop hipcc's K
-// loop carries ~150 v_mov per chunk (register copies of the patch that is read one chunk ahead) that the one-tile form does
-// not have, and 6 VGPRs + 20 SGPRs spill per tile.  Not used.
-#ifndef W4_PERSIST
-#define W4_PERSIST 0
-#endif
-#if W4_PERSIST
-#define W4_TILE_DONE break
-#else
-#define W4_TILE_DONE return
-#endif
-#ifndef W4_EARLY_U                            // 1: a pass's first B fragment is requested before its input transform, not behind it (-0.2 %)
-#define W4_EARLY_U 1
-#endif
-#ifndef W4_PRE_U1                             // 1: the second pass's first B fragment is requested before the barrier between the passes
-#define W4_PRE_U1 0                           //    (measured +0.4 %: not used)
-#endif
-#ifndef W4_FASTDIV                            // 1: tile decode by multiply-high with launch constants instead of seven software divisions
-#define W4_FASTDIV 1
-#endif
-#ifndef W4_NT_STORES                          // 1: the epilogue's output stores carry the non-temporal hint (timing experiment)
-#define W4_NT_STORES 0
-#endif
-#if W4_NT_STORES
-#define W4_ST(lv, val) __builtin_nontemporal_store((val), &(lv))
-#else
-#define W4_ST(lv, val) (lv) = (val)
-#endif
-#ifndef W4_EPI_PK                             // output transform on register pairs in packed fp32: 1 = pooling variant, 2 = plain variant too
-#define W4_EPI_PK 1
-#endif
-#ifndef W4_BIAS_ACC                           // 1: the bias rides in the accumulator of transform-domain position (1, 1) (below): -0.8 %
-#define W4_BIAS_ACC 1
-#endif
-#if W4_SWAP && !W4_BIAS_ACC
-#error "W4_SWAP needs W4_BIAS_ACC (its epilogue has no bias add)"
-#endif
-#ifndef W4_PR                                 // (tools/wino4_variants.sh sweeps these two: 5 from group 0 measured best, 35.17 ms per step;
-#define W4_PR 5                               //  4 / 6 / 10 per group 35.36 / 35.27 / 35.5, 5 from group 3 35.74)
-#define W4_PR0 0
-#endif
-constexpr int W4_PATCH_READS = W4_PR;        // patch reads of the next chunk behind each MFMA group of the second pass (30 in all),
-constexpr int W4_PATCH_FIRST = W4_PR0;       // from this group on
+// Fixed choices, each measured against its alternative per batch-64 step (profiles/NOTES.md rounds 2-4, profiles/r03_wino4_variants.txt;
+// the losing forms are kept as patches under profiles/experiments/, not as switches):
+//   * the first chunk's halo pieces go out one by one as their slots are planned; the first B fragment of a pass is requested
+//     before its input transform; the whole input transform of a pass stays in front of its first MFMA
+//   * tile decode by multiply-high with launch constants (FastDiv); tile blocks wholly inside the image store without bounds checks
+//   * the bias rides in the accumulator of transform-domain position (1, 1) (-0.8 %)
+//   * cout-major accumulators (MFMA operands swapped) for the fused-1x1 variant only: it gains 3.3 % (a lane adds its 4 couts in
+//     registers), the plain and pooling variants lose 2-4 % with the 16-byte stores that layout allows
+//   * the pooling variant runs its output transform on register pairs in packed fp32 (-0.5 ... -1.1 %; plain variant +0.2 ... 0.4 %)
+//   * the next chunk's 30 patch reads follow the second pass's MFMA groups five at a time from group 0
+//   * one workgroup per tile: a persistent tile loop measured 2.3 % slower (r03; hipcc's register copies inside the tile loop)
+constexpr int W4_PATCH_READS = 5;            // patch reads of the next chunk behind each MFMA group of the second pass (30 in all)
 constexpr int NT = 512;                      // threads per workgroup
 constexpr int REG = 32;                      // output pixels per workgroup edge
 constexpr int HP = REG + 2;                  // halo edge (rows; columns in the ordinary mode)
@@ -201,78 +148,23 @@ __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi
 
 // Copies run ahead of the arithmetic: under the FIRST pass of chunk c go the five U pieces of chunk c + 1, under the SECOND
 // pass the five halo pieces of chunk c + 2 (a chunk's patch is read one chunk ahead, below, so the halo half of an image is
-// free a whole chunk earlier than its U half).  W4_PLACE[placement][gi] = which piece (0..4 of the pass) goes out behind MFMA
-// group gi (0..17: two passes of nine groups), -1 = none.  All placements are equivalent arithmetically; hipcc's schedule of
-// the loop is not, so the placement is chosen per epilogue variant by measurement (tools/wino4_placement.sh).
-__device__ constexpr signed char W4_PLACE[16][18] = {
-    { 0, -1,  1, -1,  2, -1,  3, -1,  4,   0, -1,  1, -1,  2, -1,  3, -1,  4},    //  0 every other group
-    { 0,  1,  2,  3,  4, -1, -1, -1, -1,   0,  1,  2,  3,  4, -1, -1, -1, -1},    //  1 the first five groups
-    {-1,  0,  1,  2,  3,  4, -1, -1, -1,  -1,  0,  1,  2,  3,  4, -1, -1, -1},    //  2 five from group 1
-    {-1, -1,  0,  1,  2,  3,  4, -1, -1,  -1, -1,  0,  1,  2,  3,  4, -1, -1},    //  3 five from group 2
-    {-1, -1, -1, -1,  0,  1,  2,  3,  4,  -1, -1, -1, -1,  0,  1,  2,  3,  4},    //  4 the last five groups
-    { 0,  1, -1,  2,  3, -1,  4, -1, -1,   0,  1, -1,  2,  3, -1,  4, -1, -1},    //  5 two of every three from group 0
-    {-1,  0,  1, -1,  2,  3, -1,  4, -1,  -1,  0,  1, -1,  2,  3, -1,  4, -1},    //  6 two of every three from group 1
-    { 0,  1,  2,  3,  4, -1, -1, -1, -1,   0, -1,  1, -1,  2, -1,  3, -1,  4},    //  7 U early, halo every other group
-    { 0, -1,  1, -1,  2, -1,  3, -1,  4,   0,  1,  2,  3,  4, -1, -1, -1, -1},    //  8 U every other group, halo early
-    { 0,  1,  2,  3,  4, -1, -1, -1, -1,  -1, -1, -1, -1,  0,  1,  2,  3,  4},    //  9 U early, halo late
-    {-1, -1, -1, -1,  0,  1,  2,  3,  4,   0,  1,  2,  3,  4, -1, -1, -1, -1},    // 10 U late, halo early
-    {-1,  0, -1,  1, -1,  2, -1,  3,  4,  -1,  0, -1,  1, -1,  2, -1,  3,  4},    // 11 every other group from group 1
-    { 0,  1,  2, -1, -1,  3,  4, -1, -1,   0,  1,  2, -1, -1,  3,  4, -1, -1},    // 12 3 + 2
-    {-1,  0,  1,  2,  3,  4, -1, -1, -1,   0, -1,  1, -1,  2, -1,  3, -1,  4},    // 13
-    {-1,  0,  1, -1,  2,  3, -1,  4, -1,   0,  1,  2,  3,  4, -1, -1, -1, -1},    // 14
-    { 0, -1, -1,  1, -1,  2, -1,  3,  4,   0, -1, -1,  1, -1,  2, -1,  3,  4},    // 15
-};
-__host__ __device__ constexpr int w4_piece_at(int PL, int gi) { return W4_PLACE[PL & 15][gi]; }
-constexpr bool w4_placements_valid()                    // every row places each of the five pieces of each pass exactly once
-{
-    for (int pl = 0; pl < 16; ++pl)
-        for (int h = 0; h < 2; ++h) {
-            int seen = 0;
-            for (int g = 0; g < 9; ++g) {
-                const int k = W4_PLACE[pl][9 * h + g];
-                if (k >= 0) {
-                    if (k > 4 || (seen >> k) & 1) return false;
-                    seen |= 1 << k;
-                }
-            }
-            if (seen != 0x1f) return false;
-        }
-    return true;
-}
-static_assert(w4_placements_valid(), "W4_PLACE: each placement must issue pieces 0..4 exactly once per pass");
-constexpr int w4_default_placement(int) { return 4; }     // late copies measured best for all three epilogue variants
-static_assert(W4_PR * (9 - W4_PR0) >= 30, "the second pass must issue all 30 patch reads");
+// free a whole chunk earlier than its U half).  A pass has nine MFMA groups; the pieces go out behind its LAST five: all
+// placements are equivalent arithmetically, hipcc's schedule of the loop is not, and late copies measured best for all three
+// epilogue variants among sixteen placements (profiles/r02_wino4_placement.txt).
+constexpr int w4_piece_at(int g) { return g >= 4 ? g - 4 : -1; }     // piece (0..4) that follows MFMA group g (0..8) of a pass, -1 = none
+static_assert(W4_PATCH_READS * 9 >= 30, "the second pass must issue all 30 patch reads");
 
-// ABL: timing experiments (-DADN_EXPERIMENTS builds, ADN_WINO4_ABLATE): 1 no copies after the first chunk, 2 no patch
-// reads / transform, 4 no transform, 8 no barrier, 16 no B-fragment reads, 32 no U copies, 64 no halo copies, 128 every
-// copy reads the zero block, 256 contiguous (L1-resident) stand-in for the halo gather, 2048 no epilogue, 4096 no global
-// stores in the epilogue, 8192 first chunk's copies not awaited (prologue latency); results are wrong by design.  0 in production.
-template <int EPI, int ABL = 0, int PL = w4_default_placement(EPI)>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino4_conv_f32(const ConvArgs p_)
+template <int EPI>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino4_conv_f32(const ConvArgs p)
 {
-#if W4_PERSIST
-    // The arguments are re-read from the kernel-argument segment (scalar loads, scalar-cache hits) by every tile: kept live
-    // across the tile loop they would occupy ~60 SGPRs the K loop needs (measured: 100 SGPR + 40 VGPR spills).
-    typedef const ConvArgs __attribute__((address_space(4))) KArgs;
-    KArgs *pa = (KArgs *)__builtin_amdgcn_kernarg_segment_ptr();
-    (void)p_;
-#else
-    const ConvArgs &p = p_;
-#endif
     extern __shared__ __attribute__((aligned(16))) float smem[];   // the ONLY LDS object (two images)
     // Two source forms of the same arithmetic, chosen per epilogue by measurement (hipcc's register allocation of the K loop
     // is sensitive to what has to survive it): LEAN keeps nothing thread-id-derived alive across the loop (no scratch
     // spills: the pooling and fused-1x1 variants run 4-6 % faster); the plain variant is faster (up to 6 %) in the other
     // form, which spills 7 registers once per workgroup.
-    constexpr bool LEAN = W4_PERSIST || EPI != CONV3X3_RELU;     // (the persistent form has no registers to spare: LEAN for all)
-    constexpr bool SWP = W4_SWAP == 1 || (W4_SWAP == 2 && EPI == CONV3X3_RELU_DOT);      // cout-major accumulators (W4_SWAP above)
+    constexpr bool LEAN = EPI != CONV3X3_RELU;
+    constexpr bool SWP = EPI == CONV3X3_RELU_DOT;      // cout-major accumulators (MFMA operands swapped; header comment)
 
-#ifdef ADN_EXPERIMENTS
-    // workgroup timeline (ADN_W4_TIMELINE, p.dbg != nullptr): clock at entry / first chunk ready / loop done / stores issued /
-    // stores drained + the hardware id of the CU, written by wave 0; launch_wino4_conv prints the per-CU averages
-    unsigned long long tl0 = __builtin_amdgcn_s_memtime();
-    unsigned long long tl1 = 0, tl2 = 0, tla = 0, tlb = 0, tlc = 0, tle1 = 0, tle2 = 0;
-#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -288,33 +180,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // workgroup -> (pixel tile, cout tile): SUP consecutive ids (after the XCD remap) run together on one XCD and form
     // a supertile of gc cout tiles x gp pixel tiles, so every U slab and every halo is an L2 hit for all but one of them
     // (gc = as many cout tiles as there are, up to all 32 slots: measured 0.5 % faster than capping gc at 8)
-#if W4_PERSIST
-    // workgroup b sits on XCD b & 7 (observed round-robin placement; speed only) in slot b >> 3 and walks the ids of that XCD's
-    // range in steps of the slot count: the same 32 ids run together on an XCD as in a one-tile-per-workgroup launch
-    const int xq_ = pa->nwg_total >> 3, xr_ = pa->nwg_total & 7, xcd_ = blockIdx.x & 7;
-    const int lstart = xcd_ < xr_ ? xcd_ * (xq_ + 1) : xr_ * (xq_ + 1) + (xcd_ - xr_) * xq_;
-    const int lend = lstart + xq_ + (xcd_ < xr_ ? 1 : 0), lstep = (int)(gridDim.x >> 3);
-#pragma clang loop unroll(disable)
-    for (int lid = lstart + (int)(blockIdx.x >> 3); lid < lend; lid += lstep) {
-    asm volatile("" : "+s"(pa));                          // (opaque per tile: nothing loaded through it is hoisted out of the loop)
-    KArgs &p = *pa;
-#ifdef ADN_EXPERIMENTS
-    tl0 = __builtin_amdgcn_s_memtime();                   // (timeline: one record per tile)
-#endif
-    do {
-#else
     const int lid = xcd_remap4(blockIdx.x, gridDim.x);
-#endif
     const int pair = p.pair;                              // 1: two clips side by side in the tile (see RSL above)
     int ct, pt, tx, ty, n;
-    if (W4_FASTDIV && p.fdGc.d) {
+    if (p.fdGc.d) {
         // the seven divisions of the decode cost ~1000 clocks of every workgroup's start as software divides; the divisors are
         // launch constants, so the launcher passes their reciprocals (FastDiv, adn_internal.h)
         const int gc = p.fdGc.d, sg = lid >> 5, wl = lid & (SUP - 1);
         const int wq = fastdiv(wl, p.fdGc.d, p.fdGc.m), sq = fastdiv(sg, p.fdNcg.d, p.fdNcg.m);
         ct = (sg - sq * (int)p.fdNcg.d) * gc + (wl - wq * gc);
         pt = sq * (SUP / gc) + wq;
-        if (pt >= ((p.N + pair) >> pair) * p.tilesY * p.tilesX) W4_TILE_DONE;   // padding of the last supertile (whole workgroup)
+        if (pt >= ((p.N + pair) >> pair) * p.tilesY * p.tilesX) return;   // padding of the last supertile (whole workgroup)
         const int py = fastdiv(pt, p.fdTx.d, p.fdTx.m);
         tx = pt - py * p.tilesX;
         const int pn = fastdiv(py, p.fdTy.d, p.fdTy.m);
@@ -326,7 +202,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         const int sg = lid / SUP, wl = lid - sg * SUP;
         ct = (sg % ncg) * gc + wl % gc;
         pt = (sg / ncg) * gp + wl / gc;
-        if (pt >= ((p.N + pair) >> pair) * p.tilesY * p.tilesX) W4_TILE_DONE;   // padding of the last supertile (whole workgroup)
+        if (pt >= ((p.N + pair) >> pair) * p.tilesY * p.tilesX) return;   // padding of the last supertile (whole workgroup)
         tx = pt % p.tilesX;
         pt /= p.tilesX;
         ty = pt % p.tilesY;
@@ -334,10 +210,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
     const int gy0 = ty * REG - 1, gx0 = tx * REG - 1;
 
-#ifdef ADN_EXPERIMENTS
-    asm volatile("" ::"s"(n), "s"(ty), "s"(tx), "s"(ct));
-    tla = __builtin_amdgcn_s_memtime();                 // tile decoded
-#endif
     // U slab of the first chunk: needs no plan, flies under the index arithmetic below
     const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(static_cast<const float *>(p.wpk)) + (size_t)ct * p.nchunk * (USLOTS * 4), 0,
@@ -373,7 +245,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                           ? (unsigned)((y * s.W + x) * 8 + half * 4 + second * s.C * s.H * s.W) * 4u : OOB;   // C8 layout
         }
     };
-    if (!W4_EARLY_HALO) plan(p.s0);
     // descriptor of the current source: the image of clip n (pair mode: clips n, n + 1); soff walks its 8-channel blocks
     auto src_rsrc = [&](const auto &s) {
         const unsigned img = (unsigned)(s.C * s.H * s.W) * 4u;
@@ -397,39 +268,32 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #define W4_HALO_PIECE(k, buf)                                                                  \
     do {                                                                                       \
         float *dst_ = smem + (buf) * IMG + ((k) * NT + wave * 64) * 4;                         \
-        if (ABL & 256) dma16(hrs, (((k) * NT + tid) * 16) % 32768, hsoff, dst_);   /* contiguous stand-in for the halo gather */ \
-        else if (!(ABL & 64)) dma16(hrs, (ABL & 128) ? OOB : hcur[(k) < HR ? (k) : 0], hsoff, dst_); \
+        dma16(hrs, hcur[(k) < HR ? (k) : 0], hsoff, dst_);                                     \
     } while (0)
 #define W4_HALO_END() hsoff += cstr
     // U slab of the next chunk: UR wave-instructions (the last round exists in waves 0-3 only)
 #define W4_U_PIECE(k, buf)                                                                     \
     do {                                                                                       \
-        if ((k) * NT + wave * 64 < USLOTS && !(ABL & 32))                                      \
-            dma16(urs, (ABL & 128) ? OOB : uoff, usoff + (k) * NT * 16, smem + (buf) * IMG + (HSLOTS + (k) * NT + wave * 64) * 4); \
+        if ((k) * NT + wave * 64 < USLOTS)                                                     \
+            dma16(urs, uoff, usoff + (k) * NT * 16, smem + (buf) * IMG + (HSLOTS + (k) * NT + wave * 64) * 4); \
     } while (0)
 #define W4_U_END() usoff += USLOTS * 16
-    static_assert(HR == 5 && UR == 5, "W4_PLACE and the vmcnt immediates below assume five pieces per pass");
+    static_assert(HR == 5 && UR == 5, "w4_piece_at and the vmcnt immediates below assume five pieces per pass");
     // The halo pieces of chunk 0 go out one by one as their slots are planned (the plan is ~50 instructions per piece): the
     // first bytes are on their way ~2000 clocks before the last piece is issued.  (Chunk 0 always comes from the first source.)
-    if (W4_EARLY_HALO) {
 #pragma unroll
-        for (int k = 0; k < HR; ++k) {
-            plan(p.s0, k, k + 1);
-            W4_HALO_PIECE(k, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        W4_HALO_END();
+    for (int k = 0; k < HR; ++k) {
+        plan(p.s0, k, k + 1);
+        W4_HALO_PIECE(k, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
-
-    // after the epilogue's exchange this wave finishes cout block jh of its tile block
-    const float bias_pre = (LEAN || W4_BIAS_ACC) ? 0.f : p.bias[ct * 32 + 16 * jh + ti];
+    W4_HALO_END();
 
     f32x4 acc[2][18];                                  // [cout block: 0 = the one this wave finishes (jh), 1 = the partner's][position]
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int s = 0; s < 18; ++s) acc[j][s] = f32x4{0.f, 0.f, 0.f, 0.f};
-#if W4_BIAS_ACC
     // The bias rides in the accumulator of transform-domain position (1, 1): A^T has a column of ones there, so A^T M A adds
     // M(1,1) to all 16 outputs of a tile.  That position (p = 3*1 + 1 = 4) belongs to the waves of column half 0, for both
     // cout blocks (their sums for block 1 go to the partner wave in the epilogue): no bias load or add in the epilogue.
@@ -445,7 +309,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             acc[1][4] = f32x4{b1, b1, b1, b1};
         }
     }
-#endif
 
     // patch reads: lane (ti, q) reads channels 2q, 2q+1 (one ds_read_b64) of pixel columns jh .. jh+4 of the 6 patch rows
     // of tile (ti >> 2, ti & 3)
@@ -455,30 +318,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int a_hi = a_lo + 4;                              // rows 4-5: the next group of four halo rows
     const int b_lane = (jh * 9 * 2 * 64 + lane) * 4;        // U slab [jh][group of 2 positions][pass][q][cout%16][pos%2][cout block]
 
-    if (!W4_EARLY_HALO) {
-        W4_HALO_BEGIN(0);
-#pragma unroll
-        for (int k = 0; k < HR; ++k) W4_HALO_PIECE(k, 0);
-        W4_HALO_END();
-    }
-#ifdef ADN_EXPERIMENTS
-    tlb = __builtin_amdgcn_s_memtime();                 // first copies issued
-#endif
-    if (!(ABL & 8192)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // 8192: timing experiment, first chunk not awaited
-#if W4_BIAS_ACC
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // the bias loads above are consumed HERE (everything has landed): hipcc must not place their wait inside the K loop,
     // where a vmcnt of its own would drain the copies in flight
     asm volatile("" : "+v"(acc[0][4]), "+v"(acc[1][4]));
-#endif
-#ifdef ADN_EXPERIMENTS
-    tlc = __builtin_amdgcn_s_memtime();                 // this wave's copies landed
-#endif
     __syncthreads();
-#ifdef ADN_EXPERIMENTS
-    tl1 = __builtin_amdgcn_s_memtime();
-#endif
     // the halo of chunk 1 goes out at once (image 1 has no reader yet); from here on the halo runs two chunks ahead
-    if (p.nchunk > 1 && !(ABL & 1)) {
+    if (p.nchunk > 1) {
         W4_HALO_BEGIN(1);
 #pragma unroll
         for (int k = 0; k < HR; ++k) W4_HALO_PIECE(k, 1);
@@ -544,14 +390,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     };
     if (LEAN && !active) {                              // (the plain variant's register allocation suffers from this branch: -3 %)
         for (int c = 0; c < p.nchunk; ++c) {
-            const bool more1 = c + 1 < p.nchunk && !((ABL & 1) && c >= 1), more2 = c + 2 < p.nchunk && !(ABL & 1);
+            const bool more1 = c + 1 < p.nchunk, more2 = c + 2 < p.nchunk;
             if (more1) {
 #pragma unroll
                 for (int k = 0; k < UR; ++k) W4_U_PIECE(k, (c + 1) & 1);
                 W4_U_END();
             }
             W4_WAIT_MID();
-            if (!(ABL & 8)) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();
             if (more2) {
                 W4_HALO_BEGIN(c + 2);
 #pragma unroll
@@ -559,20 +405,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 W4_HALO_END();
             }
             W4_WAIT_END(more2);
-            if (!(ABL & 8)) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();
         }
         __syncthreads();                                // the images are free for the epilogue
-        if constexpr (ABL & 2048) W4_TILE_DONE;
         __syncthreads();                                // epilogue: exchange blocks written
         if constexpr (EPI == CONV3X3_RELU_DOT) {
             __syncthreads();
             __syncthreads();
             dot_sums();
         }
-        W4_TILE_DONE;
+        return;
     }
 
-    constexpr int abl = ABL;
     // The patch of a chunk: one read serves both passes, .x = channel 2q (pass 0), .y = channel 2q + 1 (pass 1).  It is read
     // one chunk AHEAD: the halo of chunk c + 1 is complete at the barrier between the passes of chunk c (its pieces went out
     // under the second pass of chunk c - 1); the second pass's row stage has consumed d, so its MFMA groups are followed by
@@ -593,10 +437,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             }
         }
     };
-    if (!(abl & 2)) read_patch(0, 0, 30);
+    read_patch(0, 0, 30);
 #pragma clang loop unroll(disable)                      // (also keeps hipcc from peeling the last iteration, whose copy spilled 60 registers)
     for (int c = 0; c < p.nchunk; ++c) {
-        const bool more = c + 1 < p.nchunk && !((abl & 1) && c >= 1), more2 = c + 2 < p.nchunk && !(abl & 1);
+        const bool more = c + 1 < p.nchunk, more2 = c + 2 < p.nchunk;
         const int nb = (c + 1) & 1;
         const float *sA = smem + (c & 1) * IMG;
         const float *sB = sA + HSLOTS * 4;
@@ -608,18 +452,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #define W4_LOADU_H(dst, g, hh) dst = *(lds4_cv_f32x4 *)(sB + b_lane + ((g) * 2 + (hh)) * 256)
 #define W4_LOADU(dst, g) W4_LOADU_H(dst, g, h)
 #define W4_LANDED(x) asm volatile("" ::"v"(x.w))
-            if (W4_EARLY_U && !(abl & 16) && !(W4_PRE_U1 && h == 1)) {     // the first fragment flies under the transform below
-                W4_LOADU(u[0], 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            W4_LOADU(u[0], 0);                          // the first fragment flies under the transform below
+            __builtin_amdgcn_sched_barrier(0);
             float V[18];                                // [row i of the transform domain][own column]
-            if (abl & 2) {
-#pragma unroll
-                for (int i = 0; i < 18; ++i) V[i] = (float)(i + lane);
-            } else if (abl & 4) {
-#pragma unroll
-                for (int i = 0; i < 18; ++i) V[i] = h ? d[i / 3][i % 3].y : d[i / 3][i % 3].x;
-            } else {
+            {
                 // row stage, own three outputs (rows of B^T in the header comment; L_k = pixel column jh + k)
                 if (jh == 0) {
 #pragma unroll
@@ -645,27 +481,23 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 // column stage
 #pragma unroll
                 for (int b = 0; b < 3; ++b) bt6(V[0 * 3 + b], V[1 * 3 + b], V[2 * 3 + b], V[3 * 3 + b], V[4 * 3 + b], V[5 * 3 + b]);
-#if W4_TPIN
                 // The whole transform stays in front of the pass's first MFMA (hipcc would sink each operation to the group that
                 // needs it): VALU operations woven into the MFMA stream cost more than the same operations in one block behind the
                 // barrier -- measured 34.8 (pinned) / 35.0 (sunk by the compiler) / 36.6 (whole transform of the next pass in front
                 // of the barrier) / 37.6-38.3 ms per step (row stage of the next pass under the late MFMA groups of this one).
 #pragma unroll
                 for (int i = 0; i < 18; ++i) asm volatile("" : "+v"(V[i]));
-#endif
             }
             // (the empty asm of W4_LANDED consumes the landed fragment, so the next read is issued behind that wait and flies
             // under the MFMAs)
-            if (abl & 16) u[0] = u[1] = f32x4{(float)lane, 1.f, 2.f, 3.f};
-            else if (!W4_EARLY_U && !(W4_PRE_U1 && h == 1)) W4_LOADU(u[0], 0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int g = 0; g < 9; ++g) {
                 W4_LANDED(u[g & 1]);
-                if (g < 8 && !(abl & 16)) W4_LOADU(u[(g + 1) & 1], g + 1);
+                if (g < 8) W4_LOADU(u[(g + 1) & 1], g + 1);
                 __builtin_amdgcn_sched_barrier(0);
-                if (w4_piece_at(PL, 9 * h + g) >= 0) {
-                    const int pk = w4_piece_at(PL, 9 * h + g) >= 0 ? w4_piece_at(PL, 9 * h + g) : 0;
+                if (w4_piece_at(g) >= 0) {
+                    const int pk = w4_piece_at(g) >= 0 ? w4_piece_at(g) : 0;
                     if (h == 0 && more) W4_U_PIECE(pk, nb);
                     if (h == 1 && more2) W4_HALO_PIECE(pk, c & 1);
                 }
@@ -682,19 +514,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                             __builtin_amdgcn_mfma_f32_16x16x4f32(V[2 * g + (s >> 1)], u[g & 1][s], acc[s & 1][2 * g + (s >> 1)], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (h == 1 && !(abl & 2)) {                 // unconditional (the last chunk reads a stale image): no branch, exact waitcnts
-                    if (g >= W4_PATCH_FIRST) read_patch(nb, W4_PATCH_READS * (g - W4_PATCH_FIRST), W4_PATCH_READS * (g - W4_PATCH_FIRST + 1));
+                if (h == 1) {                               // unconditional (the last chunk reads a stale image): no branch, exact waitcnts
+                    read_patch(nb, W4_PATCH_READS * g, W4_PATCH_READS * (g + 1));
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
             if (h == 0) {                               // barrier between the passes
-                if (W4_PRE_U1 && !(abl & 16)) {          // the U slab of this chunk is complete: the second pass's first fragment
-                    W4_LOADU_H(u[0], 0, 1);              // is requested on this side of the barrier
-                    __builtin_amdgcn_sched_barrier(0);
-                }
                 if (more) W4_U_END();
                 W4_WAIT_MID();
-                if (!(abl & 8)) __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_barrier();
             }
         }
 #undef W4_LOADU
@@ -702,7 +530,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #undef W4_LANDED
         if (more2) W4_HALO_END();
         W4_WAIT_END(more2);                             // image c's U half is free behind this barrier, image c + 1 complete
-        if (!(abl & 8)) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
     }
 #undef W4_HALO_BEGIN
 #undef W4_HALO_PIECE
@@ -712,17 +540,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #undef W4_WAIT_MID
 #undef W4_WAIT_END
     __syncthreads();                                    // LDS reads of every wave have landed: the images are free for the epilogue
-#ifdef ADN_EXPERIMENTS
-    tl2 = __builtin_amdgcn_s_memtime();
-#endif
 
-    if constexpr (ABL & 2048) {                         // timing experiment: no epilogue (one store keeps the accumulators alive)
-        float keep = 0.f;
-#pragma unroll
-        for (int s2 = 0; s2 < 18; ++s2) keep += acc[0][s2][0] + acc[1][s2][1];
-        if (keep == 123.456f) static_cast<float *>(p.out)[tid] = keep;
-        W4_TILE_DONE;
-    }
     // ---- epilogue ----
     // Y = A^T M A = sum over the transform-domain columns j of (A^T M)[.][j] * A^T[v][j]: each wave forms the sum over its
     // own three columns for both cout blocks, hands the partner's block over through LDS (the images are free: the loop
@@ -730,8 +548,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // (SWP: lane = (tile eti of the tile block, couts 4 eq .. 4 eq + 3 of a cout block) instead)
     const int el = (LEAN || SWP) ? lane_id() : lane;    // LEAN: lane-derived values are recomputed here (see lane_id)
     const int eti = el & 15, eq = el >> 4;
-    const float bias_r = W4_BIAS_ACC ? 0.f : LEAN ? p.bias[ct * 32 + 16 * jh + eti] : bias_pre;
-    (void)bias_r;
     auto partial = [&](const f32x4 *m, int r, float (&y)[4][4]) {
         float w[4][3];
 #pragma unroll
@@ -755,10 +571,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             }
         }
     };
-    // W4_EPI_PK: the pooling variant runs the output transform on register PAIRS (r, r + 1) in packed fp32 (half the vector
+    // PK: the pooling variant runs the output transform on register PAIRS (r, r + 1) in packed fp32 (half the vector
     // instructions); exchange piece (rp, a, bp) = {y[a][2bp] of r, r+1, y[a][2bp+1] of r, r+1}.  Measured per batch-64 step
     // (profiles/r03_wino4_variants.txt, call r03q): pooling layers -0.5...-1.1 %, plain layers +0.2...0.4 % (so: pooling only).
-    constexpr bool PK = W4_EPI_PK && !SWP && (EPI == CONV3X3_RELU_POOL || (W4_EPI_PK == 2 && EPI == CONV3X3_RELU));
+    constexpr bool PK = EPI == CONV3X3_RELU_POOL;
     auto partial2 = [&](const f32x4 *m, int rp, f32x2 (&y)[4][4]) {
         auto pr = [&](int pos) { return rp ? f32x2{m[pos][2], m[pos][3]} : f32x2{m[pos][0], m[pos][1]}; };
         f32x2 w[4][3];
@@ -803,13 +619,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         for (int a = 0; a < 4; ++a) *reinterpret_cast<f32x4 *>(xb + (r * 4 + a) * 256) = f32x4{y[a][0], y[a][1], y[a][2], y[a][3]};
     }
     }
-#ifdef ADN_EXPERIMENTS
-    tle1 = __builtin_amdgcn_s_memtime();                // exchange block written
-#endif
     __syncthreads();
-#ifdef ADN_EXPERIMENTS
-    tle2 = __builtin_amdgcn_s_memtime();                // every wave's exchange block written
-#endif
     const float *xr = smem + ((tb * 2 + (jh ^ 1)) * 16 * 64 + el) * 4;  // the partner's block: its sum for OUR cout block
     if constexpr (SWP) {
         // Register r of the partial sums is cout 4 eq + r of tile eti: the 4x4 pixels of the tile x 4 consecutive couts leave
@@ -842,7 +652,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     dw[(a * 4 + b) * 16 * 9] = ((wd[0] * yy[0][a][b] + wd[1] * yy[1][a][b]) + wd[2] * yy[2][a][b]) + wd[3] * yy[3][a][b];
             __syncthreads();
             dot_sums();
-            W4_TILE_DONE;
+            return;
         }
         const int nb = n + (pair ? bx : 0);             // pair mode: the tile blocks of column 1 belong to the next clip
         const bool clip_ok = nb < p.N;
@@ -852,7 +662,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         float *pb = (EPI == CONV3X3_RELU_POOL)
                         ? static_cast<float *>(p.pool) + (size_t)nb * Hp * Wp * p.Cout + (size_t)cblk * Hp * Wp * 8 + coff
                         : nullptr;
-        const bool interior = W4_EPI_FAST && clip_ok && ty * REG + 16 * by + 16 <= p.H && tx * REG + (pair ? 0 : 16 * bx) + 16 <= p.W;   // wave-uniform
+        const bool interior = clip_ok && ty * REG + 16 * by + 16 <= p.H && tx * REG + (pair ? 0 : 16 * bx) + 16 <= p.W;   // wave-uniform
         auto finish = [&](auto interior_tag) {          // tile blocks wholly inside the image store without bounds checks
             constexpr bool INT = decltype(interior_tag)::value;
 #pragma unroll
@@ -861,7 +671,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     const f32x4 v = {yy[0][a][b], yy[1][a][b], yy[2][a][b], yy[3][a][b]};
-                    if ((ABL & 4096) && v[0] != 123.456f) continue;
                     if (INT || (clip_ok && gyt + a < p.H && gxt + b < p.W)) *reinterpret_cast<f32x4 *>(orow + b * 8) = v;
                 }
             }
@@ -876,7 +685,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             m[r] = max4_nan(yy[r][2 * a][2 * b], yy[r][2 * a][2 * b + 1], yy[r][2 * a + 1][2 * b], yy[r][2 * a + 1][2 * b + 1]);
-                        if ((ABL & 4096) && m[0] != 123.456f) continue;
                         if (INT || (clip_ok && py < Hp && (gxt >> 1) + b < Wp)) *reinterpret_cast<f32x4 *>(prow + b * 8) = m;
                     }
                 }
@@ -901,7 +709,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             for (int a = 0; a < 4; ++a) {
                 const f32x4 o = *reinterpret_cast<const f32x4 *>(xr + (r * 4 + a) * 256);
 #pragma unroll
-                for (int b = 0; b < 4; ++b) yf[r][a][b] = wdot * relu_nan(W4_BIAS_ACC ? yf[r][a][b] + o[b] : yf[r][a][b] + o[b] + bias_r);
+                for (int b = 0; b < 4; ++b) yf[r][a][b] = wdot * relu_nan(yf[r][a][b] + o[b]);
             }
         }
         __syncthreads();                                // every wave has read its partner's exchange block
@@ -914,7 +722,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 for (int b = 0; b < 4; ++b) dw[((4 * eq + a) * 16 + 4 * r + b) * 17] = yf[r][a][b];
         __syncthreads();
         dot_sums();
-        W4_TILE_DONE;
+        return;
     }
     const int nb = n + (pair ? bx : 0);                 // pair mode: the tile blocks of column 1 belong to the next clip
     const bool clip_ok = nb < p.N;
@@ -923,7 +731,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     ? static_cast<float *>(p.pool) + (size_t)nb * Hp * Wp * p.Cout + act_off<float>(p.Cout, (long)Hp * Wp, 0, col)
                     : nullptr;
     const int gy0e = ty * REG + 16 * by + 4 * eq, gx0e = tx * REG + (pair ? 0 : 16 * bx);
-    const bool interior = W4_EPI_FAST && clip_ok && ty * REG + 16 * by + 16 <= p.H && gx0e + 16 <= p.W;       // wave-uniform
+    const bool interior = clip_ok && ty * REG + 16 * by + 16 <= p.H && gx0e + 16 <= p.W;       // wave-uniform
     auto finish = [&](auto interior_tag) {
         constexpr bool INT = decltype(interior_tag)::value;
         float *orow[4], *prow[2];
@@ -955,10 +763,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     for (int e = 0; e < 2; ++e) {
                         const float v = y[a][b][e];
                         if constexpr (INT) {
-                            if (!(ABL & 4096) || v == 123.456f) W4_ST(orow[a][(8 * rp + 4 * e + b) * 8], v);
+                            orow[a][(8 * rp + 4 * e + b) * 8] = v;
                         } else {
-                            if (clip_ok && gy + a < p.H && gx + 4 * e + b < p.W && (!(ABL & 4096) || v == 123.456f))
-                                W4_ST(ob[((size_t)(gy + a) * p.W + gx + 4 * e + b) * 8], v);
+                            if (clip_ok && gy + a < p.H && gx + 4 * e + b < p.W) ob[((size_t)(gy + a) * p.W + gx + 4 * e + b) * 8] = v;
                         }
                     }
             }
@@ -973,10 +780,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                         for (int e = 0; e < 2; ++e) {
                             const float mx = mx2[e];
                             if constexpr (INT) {
-                                if (!(ABL & 4096) || mx == 123.456f) W4_ST(prow[a][(4 * rp + 2 * e + b) * 8], mx);
+                                prow[a][(4 * rp + 2 * e + b) * 8] = mx;
                             } else {
                                 const int py = (gy >> 1) + a, px = (gx >> 1) + 2 * e + b;
-                                if (clip_ok && py < Hp && px < Wp && (!(ABL & 4096) || mx == 123.456f)) W4_ST(pb[((size_t)py * Wp + px) * 8], mx);
+                                if (clip_ok && py < Hp && px < Wp) pb[((size_t)py * Wp + px) * 8] = mx;
                             }
                         }
                     }
@@ -993,12 +800,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 const f32x4 o = *reinterpret_cast<const f32x4 *>(xr + (r * 4 + a) * 256);
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
-                    y[a][b] = relu_nan(W4_BIAS_ACC ? y[a][b] + o[b] : y[a][b] + o[b] + bias_r);
+                    y[a][b] = relu_nan(y[a][b] + o[b]);
                     if constexpr (INT) {
-                        if (!(ABL & 4096) || y[a][b] == 123.456f) W4_ST(orow[a][(4 * r + b) * 8], y[a][b]);
+                        orow[a][(4 * r + b) * 8] = y[a][b];
                     } else {
-                        if (clip_ok && gy + a < p.H && gx + b < p.W && (!(ABL & 4096) || y[a][b] == 123.456f))
-                            W4_ST(ob[((size_t)(gy + a) * p.W + gx + b) * 8], y[a][b]);
+                        if (clip_ok && gy + a < p.H && gx + b < p.W) ob[((size_t)(gy + a) * p.W + gx + b) * 8] = y[a][b];
                     }
                 }
             }
@@ -1009,10 +815,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     for (int b = 0; b < 2; ++b) {
                         const float mx = max4_nan(y[2 * a][2 * b], y[2 * a][2 * b + 1], y[2 * a + 1][2 * b], y[2 * a + 1][2 * b + 1]);
                         if constexpr (INT) {
-                            if (!(ABL & 4096) || mx == 123.456f) W4_ST(prow[a][(2 * r + b) * 8], mx);
+                            prow[a][(2 * r + b) * 8] = mx;
                         } else {
                             const int py = (gy >> 1) + a, px = (gx >> 1) + b;
-                            if (clip_ok && py < Hp && px < Wp && (!(ABL & 4096) || mx == 123.456f)) W4_ST(pb[((size_t)py * Wp + px) * 8], mx);
+                            if (clip_ok && py < Hp && px < Wp) pb[((size_t)py * Wp + px) * 8] = mx;
                         }
                     }
             }
@@ -1021,35 +827,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if (interior) finish(std::true_type{});
     else finish(std::false_type{});
     }   // !SWP
-#ifdef ADN_EXPERIMENTS
-#define W4_DBG_WRITE(rec)                                                                                          \
-    if (p_.dbg && wave == 0) {                                                                                     \
-        const unsigned long long tl3 = __builtin_amdgcn_s_memtime();                                               \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                           \
-        const unsigned long long tl4 = __builtin_amdgcn_s_memtime();                                               \
-        const unsigned hwid = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));        /* HW_REG_HW_ID */ \
-        const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));        /* HW_REG_XCC_ID */ \
-        if (lane == 0) {                                                                                           \
-            unsigned long long *o = reinterpret_cast<unsigned long long *>(p_.dbg) + (size_t)(rec) * 8;            \
-            o[0] = tl0; o[1] = tl1; o[2] = tl2; o[3] = tl3; o[4] = tl4; o[5] = ((unsigned long long)xcc << 32) | hwid; \
-            o[6] = ((tla - tl0) << 32) | ((tlb - tla) & 0xffffffffull);                                            \
-            o[7] = ((tlc - tlb) & 0xfffffull) | (((tle1 - tl2) & 0xfffffull) << 20) | (((tle2 - tl2) & 0xfffffull) << 40); \
-        }                                                                                                          \
-    }
-#else
-#define W4_DBG_WRITE(rec)
-#endif
-#if W4_PERSIST
-    } while (0);
-    // every wave has read its partner's exchange block (and the fused-1x1 table): the images may be refilled.  The stores of
-    // this tile are still draining; the next tile's first wait (vmcnt(0) in front of its first barrier) covers them.
-    __syncthreads();
-    W4_DBG_WRITE(lid)
-    }   // tiles of this workgroup
-#else
-    W4_DBG_WRITE(blockIdx.x)
-#endif
-#undef W4_DBG_WRITE
 }
 
 }  // namespace
@@ -1093,33 +870,8 @@ hipError_t launch_wino4_conv(ConvKind kind, const ConvArgs &a, hipStream_t st)
         a2.fdTy = make_fastdiv((unsigned)a2.tilesY);
     }
     a2.nwg_total = (int)nwg;
-    long grid = nwg;
-#if W4_PERSIST
-    {
-        static std::atomic<int> cus{0};                   // (one device model per process: gfx950 only, checked at handle creation)
-        int c = cus.load(std::memory_order_relaxed);
-        if (c == 0) {
-            int dv = 0;
-            if (hipGetDevice(&dv) != hipSuccess || hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dv) != hipSuccess || c < 8)
-                return hipErrorInvalidDevice;
-            c &= ~7;                                       // whole slots on each of the 8 XCDs
-            cus.store(c, std::memory_order_relaxed);
-        }
-        long want = c;
-#ifdef ADN_EXPERIMENTS
-        // timing experiment: ADN_W4_GRID_MULT workgroups per CU queue up (each walks 1/MULT of the ids a resident one would)
-        static const int mult = []() { const char *e = std::getenv("ADN_W4_GRID_MULT"); return e ? std::atoi(e) : 1; }();
-        if (mult > 1) want = (long)c * mult;
-#endif
-        if (nwg > want) grid = want;                      // one workgroup per CU walks the ids; small launches stay one tile per workgroup
-        else grid = (nwg + 7) & ~7L;
-        if (grid < 8) grid = 8;
-    }
-#endif
+    const long grid = nwg;
     a2.ablate = 0;
-#ifdef ADN_EXPERIMENTS
-    { const char *ab = std::getenv("ADN_WINO4_ABLATE"); a2.ablate = ab ? std::atoi(ab) : 0; }   // timing experiments only
-#endif
     static std::atomic<unsigned long long> attr_mask{0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
@@ -1136,95 +888,6 @@ hipError_t launch_wino4_conv(ConvKind kind, const ConvArgs &a, hipStream_t st)
         if (e3 != hipSuccess) return e3;
         attr_mask.fetch_or(bit, std::memory_order_release);
     }
-#ifdef ADN_EXPERIMENTS
-    static const bool timeline = std::getenv("ADN_W4_TIMELINE") != nullptr;
-    if (timeline && kind != CONV3X3_RELU_DOT) {
-        const size_t bytes = (size_t)nwg * 8 * sizeof(unsigned long long);
-        if (hipMalloc(&a2.dbg, bytes) != hipSuccess) return hipErrorOutOfMemory;
-        (void)hipMemset(a2.dbg, 0, bytes);
-        if (a2.ablate == 128 && kind == CONV3X3_RELU) {   // copies without memory traffic (every lane out of range): the prologue's memory share
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_conv_f32<CONV3X3_RELU, 128>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((wino4_conv_f32<CONV3X3_RELU, 128>), dim3((unsigned)grid), dim3(NT), LDS_BYTES, st, a2);
-        } else if (kind == CONV3X3_RELU_POOL)
-            hipLaunchKernelGGL(wino4_conv_f32<CONV3X3_RELU_POOL>, dim3((unsigned)grid), dim3(NT), LDS_BYTES, st, a2);
-        else
-            hipLaunchKernelGGL(wino4_conv_f32<CONV3X3_RELU>, dim3((unsigned)grid), dim3(NT), LDS_BYTES, st, a2);
-        (void)hipStreamSynchronize(st);
-        std::vector<unsigned long long> hb(bytes / 8);
-        (void)hipMemcpy(hb.data(), a2.dbg, bytes, hipMemcpyDeviceToHost);
-        (void)hipFree(a2.dbg);
-        struct Rec { unsigned long long key, t0, t1, t2, t3, t4; };
-        std::vector<Rec> recs;
-        for (long b = 0; b < nwg; ++b)
-            if (hb[b * 8 + 4]) {
-                const unsigned hw = (unsigned)hb[b * 8 + 5], xcc = (unsigned)(hb[b * 8 + 5] >> 32);
-                const unsigned long long key = ((unsigned long long)(xcc & 15) << 16) | ((hw >> 8) & 0xff);   // xcc, (se, sh, cu)
-                recs.push_back({key, hb[b * 8], hb[b * 8 + 1], hb[b * 8 + 2], hb[b * 8 + 3], hb[b * 8 + 4]});
-            }
-        std::sort(recs.begin(), recs.end(), [](const Rec &x, const Rec &y) { return x.key != y.key ? x.key < y.key : x.t0 < y.t0; });
-        double pro = 0, loop = 0, epi = 0, drain = 0, gap = 0, span = 0, dec = 0, iss = 0, land = 0, ex1 = 0, ex2 = 0;
-        for (long b = 0; b < nwg; ++b)
-            if (hb[b * 8 + 4]) {
-                dec += (double)(hb[b * 8 + 6] >> 32); iss += (double)(hb[b * 8 + 6] & 0xffffffffull); land += (double)(hb[b * 8 + 7] & 0xfffffull);
-                ex1 += (double)((hb[b * 8 + 7] >> 20) & 0xfffffull); ex2 += (double)((hb[b * 8 + 7] >> 40) & 0xfffffull);
-            }
-        long ngap = 0, ncu = 0;
-        unsigned long long first = ~0ull, last = 0;
-        for (size_t i = 0; i < recs.size(); ++i) {
-            pro += (double)(recs[i].t1 - recs[i].t0);
-            loop += (double)(recs[i].t2 - recs[i].t1);
-            epi += (double)(recs[i].t3 - recs[i].t2);
-            drain += (double)(recs[i].t4 - recs[i].t3);
-            if (i + 1 < recs.size() && recs[i + 1].key == recs[i].key) { gap += (double)((long long)(recs[i + 1].t0 - recs[i].t4)); ++ngap; }
-            if (i == 0 || recs[i].key != recs[i - 1].key) ++ncu;
-            if (recs[i].t0 < first) first = recs[i].t0;
-            if (recs[i].t4 > last) last = recs[i].t4;
-        }
-        span = (double)(last - first);
-        const double nr = recs.empty() ? 1.0 : (double)recs.size();
-        std::fprintf(stderr, "[w4 timeline] H %d W %d nchunk %d Cout %d: %zu workgroups on %ld CUs, clocks per workgroup: prologue %.0f  "
-                             "K loop %.0f (%.0f per chunk)  epilogue %.0f  store drain %.0f  gap to the next workgroup on the CU %.0f;  "
-                             "launch span %.0f clocks; prologue = decode %.0f + copies issued %.0f + landed %.0f + barrier; epilogue (wave 0) = exchange written %.0f, "
-                             "barrier passed %.0f, stores issued %.0f\n", a2.H, a2.W, a2.nchunk, a2.Cout, recs.size(), ncu, pro / nr, loop / nr,
-                     loop / nr / a2.nchunk, epi / nr, drain / nr, ngap ? gap / ngap : 0.0, span, dec / nr, iss / nr, land / nr, ex1 / nr, ex2 / nr, epi / nr);
-        return hipGetLastError();
-    }
-#endif
-#ifdef ADN_EXPERIMENTS
-    static const int place = []() { const char *e = std::getenv("ADN_W4_PLACE"); return e ? std::atoi(e) : -1; }();
-    if (place >= 0 && !a2.ablate) {
-        const void *f = nullptr;
-        switch (place * 4 + (int)kind) {
-#define W4_PL(n) case n * 4 + 0: f = reinterpret_cast<const void *>(wino4_conv_f32<CONV3X3_RELU, 0, n>); break; \
-                 case n * 4 + 1: f = reinterpret_cast<const void *>(wino4_conv_f32<CONV3X3_RELU_POOL, 0, n>); break; \
-                 case n * 4 + 3: f = reinterpret_cast<const void *>(wino4_conv_f32<CONV3X3_RELU_DOT, 0, n>); break;
-            W4_PL(0) W4_PL(1) W4_PL(2) W4_PL(3) W4_PL(4) W4_PL(5) W4_PL(6) W4_PL(7)
-            W4_PL(8) W4_PL(9) W4_PL(10) W4_PL(11) W4_PL(12) W4_PL(13) W4_PL(14) W4_PL(15)
-#undef W4_PL
-        default: return hipErrorInvalidValue;
-        }
-        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
-        if (e != hipSuccess) return e;
-        void *args[] = {&a2};
-        return hipLaunchKernel(f, dim3((unsigned)grid), dim3(NT), args, LDS_BYTES, st);
-    }
-    if (a2.ablate) {
-        const void *f = nullptr;
-        switch (a2.ablate) {
-#define W4_ABL(n) case n: f = reinterpret_cast<const void *>(wino4_conv_f32<CONV3X3_RELU, n>); break;
-            W4_ABL(1) W4_ABL(2) W4_ABL(4) W4_ABL(8) W4_ABL(16) W4_ABL(9) W4_ABL(18) W4_ABL(19) W4_ABL(27) W4_ABL(32) W4_ABL(64)
-            W4_ABL(128) W4_ABL(256) W4_ABL(2048) W4_ABL(2067) W4_ABL(4096) W4_ABL(8192)
-#undef W4_ABL
-        default: return hipErrorInvalidValue;
-        }
-        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
-        if (e != hipSuccess) return e;
-        void *args[] = {&a2};
-        return hipLaunchKernel(f, dim3((unsigned)grid), dim3(NT), args, LDS_BYTES, st);
-    }
-#endif
     static_assert(8 * (256 * 17 + 32) * sizeof(float) <= LDS_BYTES, "staging of the fused 1x1 epilogue must fit the images");
     if (kind == CONV3X3_RELU_DOT)
         hipLaunchKernelGGL(wino4_conv_f32<CONV3X3_RELU_DOT>, dim3((unsigned)grid), dim3(NT), LDS_BYTES, st, a2);

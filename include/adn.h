@@ -32,6 +32,14 @@
 
 #include <stddef.h>
 
+/* The 27 functions below are the ONLY symbols libadn.so exports: the library is built with -fvisibility=hidden and linked with
+ * a version script (audiodenoiser_amd/csrc/libadn.map: `adn_*` global, everything else local). */
+#if defined(__GNUC__)
+#define ADN_API __attribute__((visibility("default")))
+#else
+#define ADN_API
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -51,15 +59,15 @@ extern "C" {
 typedef struct adn_unet adn_unet;
 
 /* Library / diagnostics --------------------------------------------------------------------------------- */
-int adn_version(void);
-const char *adn_last_error(void);
-int adn_device_count(int *count);
+ADN_API int adn_version(void);
+ADN_API const char *adn_last_error(void);
+ADN_API int adn_device_count(int *count);
 /* Builds the constant tables the handle-free entry points need on `device`: the window / twiddle tables of `n_fft` (a power
  * of two in [64, 4096]; 0 = none) and the mel filterbank of adn_perceptual_loss.  Synchronous (blocking upload), idempotent,
  * thread-safe.  After it, every adn_stft_* / adn_istft / adn_griffin_lim call with that n_fft and adn_perceptual_loss only
  * enqueue on the caller's stream, so they can be captured into a HIP graph (e.g. adn_stft_mag_fit + adn_unet_forward, the
  * wav -> network path of the reference's test.py:94-113). */
-int adn_prepare(int device, int n_fft);
+ADN_API int adn_prepare(int device, int n_fft);
 
 /* U-Net forward: replaces UNet.forward (reference code/model.py:70-94) and everything it calls —
  * DoubleConvLayer (model.py:7-20), DownSampleLayer (model.py:23-32), UpSampleLayer (model.py:35-50). ----- */
@@ -69,38 +77,38 @@ int adn_prepare(int device, int n_fft);
  * bn.running_mean, bn.running_var; per UpSampleLayer first up.weight, up.bias; finally out.weight, out.bias).
  * This is the weight format of the reference checkpoint (train.py:142, test.py:65).  BatchNorm (eval mode,
  * eps 1e-5) is folded into the preceding convolution here.  Synchronous. */
-int adn_unet_create(adn_unet **handle, int device, const float *const *host_tensors, int n_tensors);
+ADN_API int adn_unet_create(adn_unet **handle, int device, const float *const *host_tensors, int n_tensors);
 /* Same with an explicit arithmetic type.  ADN_DTYPE_F32 (= adn_unet_create): exact-fp32 matrix cores.
  * ADN_DTYPE_F16 (BASELINE configs[4]): activations and weights stored in fp16 inside the library, fp16 MFMA
  * with fp32 accumulation; x and y stay fp32 at the boundary; outputs within 1e-2 of the fp32 path. */
 #define ADN_DTYPE_F32 0
 #define ADN_DTYPE_F16 1
-int adn_unet_create_ex(adn_unet **handle, int device, const float *const *host_tensors, int n_tensors, int dtype);
+ADN_API int adn_unet_create_ex(adn_unet **handle, int device, const float *const *host_tensors, int n_tensors, int dtype);
 /* UNet(in_channels, num_classes) as the reference declares it (code/model.py:54,56,68; its own callers use (1, 1), test.py:63):
  * the same 118 tensors with downconv1.conv.double_conv.0.weight (64, in_channels, 3, 3), out.weight (num_classes, 64, 1, 1) and
  * out.bias (num_classes).  x is then (N, in_channels, F, T) and y (N, num_classes, F, T), both NCHW fp32.  1 <= in_channels <= 15
  * (and in_channels * (T + 2) <= 4096), 1 <= num_classes <= 64.  With more than one input plane / class the first / last
  * convolution run as their own launches (the fused forms are for one plane / one class). */
-int adn_unet_create_general(adn_unet **handle, int device, const float *const *host_tensors, int n_tensors, int dtype,
+ADN_API int adn_unet_create_general(adn_unet **handle, int device, const float *const *host_tensors, int n_tensors, int dtype,
                             int in_channels, int num_classes);
-int adn_unet_channels(const adn_unet *handle, int *in_channels, int *num_classes);
-int adn_unet_destroy(adn_unet *handle);
+ADN_API int adn_unet_channels(const adn_unet *handle, int *in_channels, int *num_classes);
+ADN_API int adn_unet_destroy(adn_unet *handle);
 
 /* Bytes of device scratch adn_unet_forward needs for an (N,1,F,T) batch (half as much for an fp16 handle;
  * handle may be NULL = fp32). */
-int adn_unet_workspace_bytes(const adn_unet *handle, int N, int F, int T, size_t *bytes);
+ADN_API int adn_unet_workspace_bytes(const adn_unet *handle, int N, int F, int T, size_t *bytes);
 
 /* y(N,K,F,T) = UNet(x(N,C,F,T)) (C = K = 1 unless the handle came from adn_unet_create_general), eval-mode semantics
  * (BatchNorm uses running statistics), fp32.
  * x, y, workspace: device memory on the handle's device.  F,T >= 16 (four 2x poolings). */
 /* Shape limits: N >= 1, F >= 16, 16 <= T <= 4094, F*T < 2^24 (ADN_ERR_INVALID otherwise). */
-int adn_unet_forward(adn_unet *handle, const float *x, float *y, int N, int F, int T,
+ADN_API int adn_unet_forward(adn_unet *handle, const float *x, float *y, int N, int F, int T,
                      void *workspace, size_t workspace_bytes, void *stream);
 
 /* Same, additionally exporting block outputs as NCHW fp32 device tensors for parity tests: taps[i] may be
  * NULL (skipped) or a buffer of the block's size, i = 0..3 skip tensors down1..4 (DownSampleLayer's first
  * return value), 4 bottleneck, 5..8 up1..4, 9 out. */
-int adn_unet_forward_taps(adn_unet *handle, const float *x, float *y, int N, int F, int T,
+ADN_API int adn_unet_forward_taps(adn_unet *handle, const float *x, float *y, int N, int F, int T,
                           void *workspace, size_t workspace_bytes, float *const *taps, void *stream);
 
 /* Measurement hook (bench.py's roofline object): with timing enabled every kernel launch of adn_unet_forward
@@ -109,16 +117,16 @@ int adn_unet_forward_taps(adn_unet *handle, const float *x, float *y, int N, int
  * (0-based since the last adn_unet_set_timing) and returns the ADN_N_LAUNCHES kernel durations in
  * milliseconds, in launch order: conv_first; conv3x3+pool (down1); [conv3x3, conv3x3+pool] x3 (down2..4);
  * conv3x3 x2 (bottleneck); [convT, conv3x3(cat), conv3x3] x4 (up1..4); conv1x1 out. */
-int adn_unet_set_timing(adn_unet *handle, int max_forwards);
-int adn_unet_get_timing(adn_unet *handle, int index, float *ms);
+ADN_API int adn_unet_set_timing(adn_unet *handle, int max_forwards);
+ADN_API int adn_unet_get_timing(adn_unet *handle, int index, float *ms);
 
 /* STFT magnitude: replaces audio_to_magnitude_spectrogram (code/create_train_dataset.py:162-174,
  * center=0) and audio_to_spectrogram (code/create_test_dataset.py:35-41, center=1), i.e.
  * librosa.stft(y, n_fft, hop_length, center, window="hann", pad_mode="constant") + librosa.magphase. ------- */
-int adn_stft_n_frames(long length, int n_fft, int hop, int center, long *n_frames);
+ADN_API int adn_stft_n_frames(long length, int n_fft, int hop, int center, long *n_frames);
 /* audio (n_clips, length) fp32 -> out (n_clips, n_fft/2+1, n_frames) fp32, frame index fastest.
  * n_fft: power of two in [64, 4096]; hop >= 1. */
-int adn_stft_mag(const float *audio, int n_clips, long length, int n_fft, int hop, int center,
+ADN_API int adn_stft_mag(const float *audio, int n_clips, long length, int n_fft, int hop, int center,
                  float *out, void *stream);
 
 /* STFT magnitude fused with the loader rule that follows it on the wav -> network path: out (n_clips, H, W) =
@@ -126,17 +134,17 @@ int adn_stft_mag(const float *audio, int n_clips, long length, int n_fft, int ho
  * (code/data_loader.py:41-42,54-72 applied to code/create_test_dataset.py:35-41) in one kernel: only the min(n_frames, W)
  * frames inside the window are computed, nothing is written outside it, rows are W floats apart.  Bit-identical to the
  * two-step form. */
-int adn_stft_mag_fit(const float *audio, int n_clips, long length, int n_fft, int hop, int center,
+ADN_API int adn_stft_mag_fit(const float *audio, int n_clips, long length, int n_fft, int hop, int center,
                      float *out, int H, int W, void *stream);
 
 /* Loader arithmetic: replaces SpectrogramDataset.__getitem__/_pad_or_truncate (code/data_loader.py:41-42,
  * 54-72) for a batch already on the device: out(n,H,W) = fp32(fp16(in(n,h,w))) cropped / zero padded at the
  * bottom and right. */
-int adn_quantize_pad(const float *in, int n, int h, int w, float *out, int H, int W, void *stream);
+ADN_API int adn_quantize_pad(const float *in, int n, int h, int w, float *out, int H, int W, void *stream);
 
 /* Per-clip mean absolute error, the payload of the multi-GPU all-gather (F.l1_loss per clip, cf.
  * code/loss.py:86):  out[i] = mean_j |a[i,j] - b[i,j]|. */
-int adn_per_clip_l1(const float *a, const float *b, int n_clips, long elems_per_clip, float *out, void *stream);
+ADN_API int adn_per_clip_l1(const float *a, const float *b, int n_clips, long elems_per_clip, float *out, void *stream);
 
 /* Per-clip CombinedPerceptualLoss: replaces, clip by clip, CombinedPerceptualLoss.forward and the two losses it
  * calls (code/loss.py:6-95; caller code/test.py:118-122).  pred, target: (n_clips,1,F,T) fp32 device tensors;
@@ -146,8 +154,8 @@ int adn_per_clip_l1(const float *a, const float *b, int n_clips, long elems_per_
  * frames are held in the 160 KiB LDS of one CU; ADN_ERR_INVALID outside, before anything is enqueued) and
  * adn_perceptual_loss_workspace_bytes of device scratch. */
 #define ADN_LOSS_MAX_FRAMES 6784
-int adn_perceptual_loss_workspace_bytes(int n_clips, int F, int T, size_t *bytes);
-int adn_perceptual_loss(const float *pred, const float *target, int n_clips, int F, int T, void *workspace,
+ADN_API int adn_perceptual_loss_workspace_bytes(int n_clips, int F, int T, size_t *bytes);
+ADN_API int adn_perceptual_loss(const float *pred, const float *target, int n_clips, int F, int T, void *workspace,
                         size_t workspace_bytes, float *out, void *stream);
 
 /* ---- inverse STFT and Griffin-Lim ----------------------------------------------------------------------------
@@ -158,15 +166,15 @@ int adn_perceptual_loss(const float *pred, const float *target, int n_clips, int
  * magnitude, rnd: device (n_clips, n_bins, n_frames) fp32 [the reference's (F, T) layout]; audio_out: device
  * (n_clips, hop*(n_frames-1)) fp32.  Complex spectrograms of the building blocks below are FRAME-major:
  * (n_clips, n_frames, n_bins, 2) fp32. */
-int adn_istft_length(int n_frames, int hop, long *length);
-int adn_griffin_lim_workspace_bytes(int n_clips, int n_bins, int n_frames, size_t *bytes);
-int adn_griffin_lim(const float *magnitude, const float *rnd, int n_clips, int n_bins, int n_frames, int n_fft, int hop,
+ADN_API int adn_istft_length(int n_frames, int hop, long *length);
+ADN_API int adn_griffin_lim_workspace_bytes(int n_clips, int n_bins, int n_frames, size_t *bytes);
+ADN_API int adn_griffin_lim(const float *magnitude, const float *rnd, int n_clips, int n_bins, int n_frames, int n_fft, int hop,
                     int iterations, void *workspace, size_t workspace_bytes, float *audio_out, void *stream);
 /* librosa.stft(audio, n_fft, hop) complex result, centred: n_frames = 1 + length/hop (test.py:41-43). */
-int adn_stft_complex(const float *audio, int n_clips, long length, int n_fft, int hop, float *spec_out, void *stream);
+ADN_API int adn_stft_complex(const float *audio, int n_clips, long length, int n_fft, int hop, float *spec_out, void *stream);
 /* librosa.istft(spec, hop_length=hop) (test.py:40,48); workspace = n_clips*n_frames*n_fft floats. */
-int adn_istft_workspace_bytes(int n_clips, int n_frames, int n_fft, size_t *bytes);
-int adn_istft(const float *spec, int n_clips, int n_frames, int n_fft, int hop, void *workspace, size_t workspace_bytes,
+ADN_API int adn_istft_workspace_bytes(int n_clips, int n_frames, int n_fft, size_t *bytes);
+ADN_API int adn_istft(const float *spec, int n_clips, int n_frames, int n_fft, int hop, void *workspace, size_t workspace_bytes,
               float *audio_out, void *stream);
 
 #ifdef __cplusplus

@@ -212,7 +212,8 @@ def test_nonfinite_clip_poisons_neither_its_neighbours_nor_the_next_call(dev, go
     from audiodenoiser_amd.weights import make_input
     m = _net(weights_np, dev, dtype)
     f, t = 513, 256
-    clean = torch.from_numpy(make_input(7, 4, f, t)).to(dev)
+    base = make_input(7, 4, f, t)                              # clip 0 of it is the goldens' input: placed SECOND in the batch
+    clean = torch.from_numpy(np.ascontiguousarray(base[[1, 0, 2, 3]])).to(dev)
     with torch.no_grad():
         y0 = m(clean).clone()
         bad = clean.clone()

@@ -23,6 +23,12 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), f"libadn.so does not export {name}"
     assert declared == set(_lib.EXPORTED_SYMBOLS)
     assert L.adn_version() >= 1
+    # ... and NOTHING else: the dynamic symbol table holds exactly the header's functions (no internal launchers, no weak
+    # instantiations of C++ runtime templates) -- -fvisibility=hidden + csrc/libadn.map
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", L._name], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1].split("@")[0] for ln in out.splitlines() if ln.split() and ln.split()[-2] in "TWVBDR"}
+    assert exported == declared, sorted(exported ^ declared)
 
 
 def test_host_only_entry_points_and_errors():
