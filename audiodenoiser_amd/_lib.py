@@ -47,6 +47,7 @@ def load() -> ctypes.CDLL:
         L.adn_unet_create_ex.argtypes = [ctypes.POINTER(vp), ci, ctypes.POINTER(c_float_p), ci, ci]
         L.adn_unet_create_general.argtypes = [ctypes.POINTER(vp), ci, ctypes.POINTER(c_float_p), ci, ci, ci, ci]
         L.adn_unet_channels.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci)]
+        L.adn_unet_set_batch_invariant.argtypes = [vp, ci]
         L.adn_unet_destroy.argtypes = [vp]
         L.adn_unet_workspace_bytes.argtypes = [vp, ci, ci, ci, ctypes.POINTER(sz)]
         L.adn_unet_forward.argtypes = [vp, vp, vp, ci, ci, ci, vp, sz, vp]
@@ -67,7 +68,7 @@ def load() -> ctypes.CDLL:
         L.adn_istft_workspace_bytes.argtypes = [ci, ci, ci, ctypes.POINTER(sz)]
         L.adn_istft.argtypes = [vp, ci, ci, ci, ci, vp, sz, vp, vp]
         for name in ("adn_device_count", "adn_prepare", "adn_unet_create", "adn_unet_create_ex", "adn_unet_create_general", "adn_unet_channels",
-                     "adn_unet_destroy", "adn_unet_workspace_bytes", "adn_unet_forward", "adn_unet_forward_taps", "adn_unet_set_timing", "adn_unet_get_timing",
+                     "adn_unet_set_batch_invariant", "adn_unet_destroy", "adn_unet_workspace_bytes", "adn_unet_forward", "adn_unet_forward_taps", "adn_unet_set_timing", "adn_unet_get_timing",
                      "adn_stft_n_frames", "adn_stft_mag", "adn_stft_mag_fit", "adn_quantize_pad", "adn_per_clip_l1",
                      "adn_perceptual_loss_workspace_bytes", "adn_perceptual_loss", "adn_istft_length",
                      "adn_griffin_lim_workspace_bytes", "adn_griffin_lim", "adn_stft_complex",
@@ -96,7 +97,7 @@ def check(rc: int, what: str) -> None:
 
 EXPORTED_SYMBOLS = (
     "adn_version", "adn_last_error", "adn_device_count", "adn_prepare", "adn_unet_create", "adn_unet_create_ex", "adn_unet_create_general",
-    "adn_unet_channels", "adn_unet_destroy", "adn_unet_workspace_bytes", "adn_unet_forward", "adn_unet_forward_taps", "adn_unet_set_timing",
+    "adn_unet_channels", "adn_unet_set_batch_invariant", "adn_unet_destroy", "adn_unet_workspace_bytes", "adn_unet_forward", "adn_unet_forward_taps", "adn_unet_set_timing",
     "adn_unet_get_timing", "adn_stft_n_frames", "adn_stft_mag", "adn_stft_mag_fit",
     "adn_quantize_pad", "adn_per_clip_l1", "adn_perceptual_loss_workspace_bytes", "adn_perceptual_loss",
     "adn_istft_length", "adn_griffin_lim_workspace_bytes", "adn_griffin_lim", "adn_stft_complex",

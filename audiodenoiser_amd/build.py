@@ -36,15 +36,9 @@ FILE_FLAGS = {"wino4_kernels.hip": ["-fno-slp-vectorize"]}
 
 
 def _extra_flags():
-    """``ADN_BUILD_EXPERIMENTS=1`` compiles the timing-experiment switches in (ablations, in-kernel stamps, A/B
-    tilings; ``-DADN_EXPERIMENTS``).  The production library contains none of them."""
-    flags = []
-    if os.environ.get("ADN_BUILD_EXPERIMENTS", "") not in ("", "0"):
-        flags.append("-DADN_EXPERIMENTS")
-        if os.environ.get("ADN_BUILD_STAMPS", "") not in ("", "0"):
-            flags.append("-DADN_WINO_STAMPS")
-        flags += os.environ.get("ADN_BUILD_DEFINES", "").split()      # experiments only: extra -D switches of a sweep
-    return flags
+    """Extra ``-D`` switches of a local A/B build (``ADN_BUILD_DEFINES``); empty for the production library, whose sources carry
+    no timing-experiment code (closed experiments are kept as patches under ``profiles/experiments/``)."""
+    return os.environ.get("ADN_BUILD_DEFINES", "").split()
 
 
 def _sources():
@@ -191,20 +185,18 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
-def build_variant(name: str, defines, experiments: bool = True) -> str:
-    """Cross-compile a build-time VARIANT of the library (extra -D switches, by default with the experiment switches
-    compiled in) to ``_lib/variants/libadn_<name>.so`` without touching the production library.  Variant sweeps are
-    compiled in the build container and shipped to the GPU box with the tree; a process picks one with
-    ``ADN_LIBADN_PATH`` (see ``_lib.load``).  Tools only: nothing in the product path sets that variable.
-    NOTE for A/B runs: an experiments variant is 2-3 % slower than the production library built from the same source (the
-    ablation switches are run-time tests inside the kernels) -- compare variants with variants, or pass ``--production``."""
+def build_variant(name: str, defines) -> str:
+    """Cross-compile a build-time VARIANT of the library (extra -D switches of a work-in-progress A/B) to
+    ``_lib/variants/libadn_<name>.so`` without touching the production library.  Variants are compiled in the build container
+    and shipped to the GPU box with the tree; a process picks one with ``ADN_LIBADN_PATH`` (see ``_lib.load``).  Tools only:
+    nothing in the product path sets that variable."""
     hipcc = hipcc_path()
     if hipcc is None:
         raise RuntimeError("hipcc not found")
     vdir = os.path.join(LIBDIR, "variants")
     os.makedirs(vdir, exist_ok=True)
     dst = os.path.join(vdir, f"libadn_{name}.so")
-    flags = (["-DADN_EXPERIMENTS"] if experiments else []) + list(defines)
+    flags = list(defines)
     with tempfile.TemporaryDirectory(prefix="adn_variant_") as objdir:
         def compile_one(src):
             obj = os.path.join(objdir, os.path.basename(src) + ".o")
@@ -219,6 +211,6 @@ def build_variant(name: str, defines, experiments: bool = True) -> str:
 
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "--variant":          # python -m audiodenoiser_amd.build --variant NAME [-D...]
-        print(build_variant(sys.argv[2], [a for a in sys.argv[3:] if a != "--production"], "--production" not in sys.argv))
+        print(build_variant(sys.argv[2], [a for a in sys.argv[3:] if a != "--production"]))
     else:
         print(build(force="--force" in sys.argv, verbose=True))

@@ -127,7 +127,6 @@ struct adn_unet {
     // workgroups, is level at 160 and loses by 25-50 % from 240 on; the 64-channel full-resolution layers (8-chunk K loops,
     // where the prologue and epilogue of the 32x32-tile kernel weigh most, and down1 can take the first convolution in) switch at 512
     long auto_grid = 192, auto_grid64 = 512;
-    size_t zeros_off = 0;          // 64 zero floats inside the packed buffer
 };
 
 namespace {
@@ -401,10 +400,7 @@ adn::ConvArgs conv_args(const adn_unet *h, const Conv3x3Layer &L, adn::ConvKind 
     a.tilesY = (H + g.TH - 1) / g.TH;
     a.tilesX = (W + 15) / 16;
     a.nct = L.Cout / g.BN;
-    a.ablate = 0;
     a.pair = 0;
-    a.zeros = h->dev + h->zeros_off;
-    a.dbg = nullptr;
     a.ksplit = 1;
     a.nwg_base = 0;
     a.partial = nullptr;
@@ -600,10 +596,7 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
         t.tilesY = (uh + g.TH - 1) / g.TH;
         t.tilesX = (uw + 15) / 16;
         t.nct = 4 * co / g.BN;
-        t.ablate = 0;
         t.pair = 0;
-        t.zeros = h->dev + h->zeros_off;
-        t.dbg = nullptr;
         t.ksplit = 1;
         t.nwg_base = 0;
         t.partial = nullptr;
@@ -727,6 +720,13 @@ int adn_unet_channels(const adn_unet *h, int *in_channels, int *num_classes)
     return ADN_OK;
 }
 
+int adn_unet_set_batch_invariant(adn_unet *h, int on)
+{
+    if (!h) return fail(ADN_ERR_INVALID, "adn_unet_set_batch_invariant: null handle");
+    h->batch_invariant = on != 0;
+    return ADN_OK;
+}
+
 int adn_unet_create_general(adn_unet **handle, int device, const float *const *t, int n_tensors, int dtype, int in_channels,
                             int num_classes)
 {
@@ -774,7 +774,6 @@ int adn_unet_create_general(adn_unet **handle, int device, const float *const *t
         return at;
     };
     std::vector<float> scale, bias;
-    h->zeros_off = reserve(64);
 
     // tensor table walk (state_dict order, see adn.h)
     int ti = 0, li = 0;

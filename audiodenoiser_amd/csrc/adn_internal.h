@@ -87,9 +87,6 @@ struct ConvArgs {
     int nwg_total;         // wino4_conv_f32 only: logical workgroup ids (= tiles incl. supertile padding) of the launch
     int split;             // fp32 transposed convolution only: 1 = weights are three bf16 planes (pack_convt_split), the contraction
                            // runs as six bf16 MFMA products per term pair with fp32 accumulation (conv_dma<..., SPLIT>)
-    int ablate;            // timing experiments only (ADN_WINO_ABLATE); 0 in production
-    const float *zeros;    // >= 16 bytes of zeros in device memory (source of padding lanes of the LDS-DMA copy)
-    void *dbg;             // diagnostic stamp buffer (ADN_WINO_STAMP); nullptr in production
     // split-K (small batches, Winograd kernel only): `ksplit` workgroups share one output tile, each sums a slice
     // of nchunk/ksplit chunks and writes raw partial sums to `partial` [split][N][H][W][Cout]; a second launch adds
     // them in a fixed order and applies bias / ReLU / pooling.  ksplit = 1: everything in one launch.

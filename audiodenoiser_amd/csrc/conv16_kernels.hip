@@ -47,9 +47,7 @@ constexpr int C16_W_SLOTS = 9 * 4 * 64;           // weight slab of a chunk: [ta
 constexpr int C16_HPIECES = C16_HALO_SLOTS / 64 / 8;       // halo copies per wave and chunk (5)
 constexpr int C16_WPIECES = (C16_W_SLOTS / 64 + 7) / 8;    // weight copies per wave and chunk (5, the last half used)
 
-#ifndef C16_PPT
-#define C16_PPT 2                                 // copies issued per tap (from tap 0 on)
-#endif
+constexpr int C16_PPT = 2;                        // copies issued per tap (from tap 0 on)
 constexpr int C16_B_SLOTS = 64;                   // one wave copy: the 64 biases of the cout tile in the first 16 slots
 // FIRST (down1's second conv, model.py:11-16 via :56): the 64-channel input of the layer is never read -- the halo image of a chunk
 // is COMPUTED from the network input by the first convolution Conv2d(1 -> 64) + BN + ReLU on the same matrix cores (K = 32 =
@@ -346,7 +344,7 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
     fetch_advance();
 
     // ---- compute side ----
-    int c_item = first, c_chunk = 0, c_k = 0;
+    int c_item = first, c_k = 0;
     C16Item ci = c16_decode(p, c_item);
     f32x4 acc[4][4];                                // [pixel row block i][cout block j]: lane = (pixel l16, couts 4g .. 4g+3)
 
@@ -363,14 +361,8 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-#ifdef ADN_EXPERIMENTS
-    // step timeline (ADN_C16_TIMELINE, p.dbg != nullptr): per wave, clocks summed over the steps: start -> last MFMA issued ->
-    // own copies landed (vmcnt) -> barrier passed; launch_c16 prints the averages
-    const bool tl_on = p.dbg != nullptr;
-    unsigned long long tl_c = 0, tl_sum[3] = {0, 0, 0}, tl_0 = tl_on ? __builtin_amdgcn_s_memtime() : 0, tl_first = tl_0;
-#endif
     // one step = one 32-channel chunk of one item; PAR = parity of the step = the LDS image it computes from
-    // ROLE of the step inside its item: 1 = first chunk, 2 = a middle one, 3 = the last, 0 = decided at run time (c_chunk)
+    // ROLE of the step inside its item: 1 = first chunk, 2 = a middle one, 3 = the last
     auto step = [&](auto par_tag, auto role_tag, const int s) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par_tag)::value;
         constexpr int ROLE = decltype(role_tag)::value;
@@ -378,13 +370,13 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
         const bool more = s + 1 < nsteps;
         const unsigned kill = more ? 0u : ADN_DMA_OOB;       // last step: the copies run on and fetch nothing
         const char *img = img_base + buf * IMG_B;
-        // CT: the step's place in its item is a compile-time fact (ROLE; an item is an even number of steps, so parities are
-        // fixed too): the epilogue exists in the last step only -- where hipcc then weaves it into the trailing MFMAs -- and the
-        // first one starts its accumulators from the bias as the C operand of its first MFMAs instead of 64 copies.  The FIRST
-        // form, at 225 VGPRs, would spill that way: it keeps the run-time form (ROLE 0).
-        constexpr bool CT = ROLE != 0;
-        const bool first_chunk = CT ? ROLE == 1 : c_chunk == 0;
-        const char *wimg = WRES ? smem16 + (CT ? PAR : c_chunk) * (C16_W_SLOTS * 16) : img + C16_HALO_SLOTS * 16;
+        // The step's place in its item is a compile-time fact (ROLE; an item is an even number of steps, so parities are fixed
+        // too): the epilogue exists in the last step only -- where hipcc then weaves it into the trailing MFMAs -- and the first
+        // one starts its accumulators from the bias as the C operand of its first MFMAs instead of 64 copies.  (Every form,
+        // the FIRST one included: two steps per item, roles 1 and 3.)
+        static_assert(ROLE >= 1 && ROLE <= 3, "step role");
+        constexpr bool first_chunk = ROLE == 1;
+        const char *wimg = WRES ? smem16 + PAR * (C16_W_SLOTS * 16) : img + C16_HALO_SLOTS * 16;
         bool win_pending = false;
         if constexpr (FIRST) {
             // first step of an item: the NEXT item's window starts its trip (its first halo is computed in the next step)
@@ -398,13 +390,7 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
         if (first_chunk) {
             const char *bl = (WRES ? smem16 : img) + BIAS_OFF + g * 16;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                biasv[j] = *reinterpret_cast<const f32x4 *>(bl + j * 64);
-                if constexpr (!CT) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[i][j] = biasv[j];
-                }
-            }
+            for (int j = 0; j < 4; ++j) biasv[j] = *reinterpret_cast<const f32x4 *>(bl + j * 64);
         }
         // Fragment reads.  The X fragment of (row block i, tap (dy, dx)) is halo row 4 wave + i + dy at column offset dx: for one
         // dx the six rows 4 wave .. 4 wave + 5 serve all twelve (i, dy) pairs, so the taps are walked dx-major -- 6 X + 12 W
@@ -419,55 +405,36 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
 #pragma unroll
             for (int j = 0; j < 4; ++j) wf[slot][j] = *reinterpret_cast<const f16x8 *>(wimg + w_lane + (tap * 4 + j) * 1024);
         };
-#ifdef ADN_EXPERIMENTS
-        // timing experiments (ADN_C16_ABLATE, results wrong by design): 1 = no fragment reads / MFMAs, 2 = no copies after the
-        // prologue, 4 = no epilogue stores
-        const int abl = p.ablate;
-#else
-        constexpr int abl = 0;
-#endif
-        if (!(abl & 1)) {
-            load_x(0, 0);
-            load_w(0, 0);
-        }
+        load_x(0, 0);
+        load_w(0, 0);
 #pragma unroll
         for (int tp = 0; tp < 9; ++tp) {
             const int dx = tp / 3, dy = tp % 3;
-            if (!(abl & 1)) {
-                if (tp < 8) load_w(tp + 1, (tp + 1) & 1);
-                if (dy == 1 && dx < 2) load_x(dx + 1, (dx + 1) & 1);
-            }
+            if (tp < 8) load_w(tp + 1, (tp + 1) & 1);
+            if (dy == 1 && dx < 2) load_x(dx + 1, (dx + 1) & 1);
             // the next step's copies go out between the first taps' MFMA groups (PPT per tap): the last one has the rest of
             // the step to land before the wait at its end
-            if ((!FIRST || more) && !(abl & 2)) {          // (FIRST: the "pieces" are computed halo blocks -- skipped, not killed)
+            if (!FIRST || more) {                          // (FIRST: the "pieces" are computed halo blocks -- skipped, not killed)
 #pragma unroll
                 for (int q = tp * PPT; q < (tp + 1) * PPT; ++q)
                     if (q < NPIECE) fetch_piece(q, buf ^ 1, kill);
             }
-#ifdef ADN_EXPERIMENTS
-            if (tp == 8 && tl_on) tl_c = __builtin_amdgcn_s_memtime();
-#endif
             // fetch bookkeeping (next chunk / next item: decode + the halo plan) once the last copy is out, between MFMA groups
             // instead of in the tail of the step, where both waves of a SIMD would do it with the matrix pipe idle
             if (tp == (NPIECE - 1) / PPT + 1 && more) fetch_advance();
-            if (!(abl & 1)) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tp & 1][j], xr[dx & 1][i + dy],
-                                                                           (ROLE == 1 && tp == 0) ? biasv[j] : acc[i][j], 0, 0, 0);
-            }
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tp & 1][j], xr[dx & 1][i + dy],
+                                                                       (ROLE == 1 && tp == 0) ? biasv[j] : acc[i][j], 0, 0, 0);
         }
 
-        bool last_chunk;
-        if constexpr (CT) last_chunk = ROLE == 3;
-        else last_chunk = ++c_chunk == nchunk;
+        constexpr bool last_chunk = ROLE == 3;
         if (last_chunk) {
             // ---- epilogue of the item: ReLU, 8-byte stores straight from the accumulators, through buffer descriptors (a lane
             // outside the image stores out of range = nowhere): no branches, a fixed number of stores, so the wait below can
             // leave exactly them in flight ----
-            c_chunk = 0;
             const int gx = ci.tx * C16_TW + l16;
             const int gyb = ci.ty * C16_TH + wave * 4;
             // ReLU as torch.relu computes it (relu_nan, adn_internal.h: one v_maximum3_f32): NaN stays NaN, +inf stays +inf, -inf
@@ -493,7 +460,7 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
                     float v = part[i];
                     v += __shfl_xor(v, 16, 64);
                     v += __shfl_xor(v, 32, 64);
-                    const unsigned off = ((g == 0) & (gyb + i < p.H) & (gx < p.W) & !(abl & 4)) ? (unsigned)(((gyb + i) * p.W + gx) * 4) : ADN_DMA_OOB;
+                    const unsigned off = ((g == 0) & (gyb + i < p.H) & (gx < p.W)) ? (unsigned)(((gyb + i) * p.W + gx) * 4) : ADN_DMA_OOB;
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v + p.dot_bias), yrs, off, 0, 0);
                 }
             } else {
@@ -507,7 +474,7 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
                 unsigned ooff[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    ooff[i] = ((gyb + i < p.H) & (gx < p.W) & !(abl & 4)) ? (unsigned)(((gyb + i) * p.W + gx) * 32 + g * 8) : ADN_DMA_OOB;
+                    ooff[i] = ((gyb + i < p.H) & (gx < p.W)) ? (unsigned)(((gyb + i) * p.W + gx) * 32 + g * 8) : ADN_DMA_OOB;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const unsigned cb = (unsigned)__builtin_amdgcn_readfirstlane((ci.ct * 4 + j) * (int)HWb);
@@ -535,7 +502,7 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
                                 m[d] = __builtin_bit_cast(unsigned, __builtin_elementwise_maximum(t, __builtin_bit_cast(f16x2, ou)));
                             }
                             const int py = (gyb >> 1) + a, px = gx >> 1;
-                            const unsigned poff = (!(l16 & 1) & (py < Hp) & (px < Wp) & !(abl & 4)) ? (unsigned)((py * Wp + px) * 32 + g * 8) : ADN_DMA_OOB;
+                            const unsigned poff = (!(l16 & 1) & (py < Hp) & (px < Wp)) ? (unsigned)((py * Wp + px) * 32 + g * 8) : ADN_DMA_OOB;
                             __builtin_amdgcn_raw_buffer_store_b64(m, prs, poff, cbp, 0);
                         }
                     }
@@ -565,19 +532,8 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
         }
-#ifdef ADN_EXPERIMENTS
-        unsigned long long tl_w = 0;
-        if (tl_on) tl_w = __builtin_amdgcn_s_memtime();
-#endif
         // all waves: image `buf` is free, image `buf ^ 1` complete
         asm volatile("s_barrier" ::: "memory");
-#ifdef ADN_EXPERIMENTS
-        if (tl_on) {
-            const unsigned long long tl_b = __builtin_amdgcn_s_memtime();
-            tl_sum[0] += tl_c - tl_0; tl_sum[1] += tl_w - tl_c; tl_sum[2] += tl_b - tl_w;
-            tl_0 = tl_b;
-        }
-#endif
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
@@ -600,12 +556,6 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
             step(I1{}, std::integral_constant<int, 3>{}, s++);
         }
     }
-#ifdef ADN_EXPERIMENTS
-    if (tl_on && lane == 0) {
-        unsigned long long *o = reinterpret_cast<unsigned long long *>(p.dbg) + ((size_t)blockIdx.x * 8 + wave) * 8;
-        o[0] = tl_sum[0]; o[1] = tl_sum[1]; o[2] = tl_sum[2]; o[3] = (unsigned long long)nsteps; o[4] = tl_0 - tl_first;
-    }
-#endif
 }
 
 template <int EPI, bool WRES, bool FIRST = false>
@@ -625,10 +575,6 @@ hipError_t launch_c16(const ConvArgs &a, hipStream_t st)
     a2.fdTx = make_fastdiv((unsigned)a2.tilesX);
     a2.fdTy = make_fastdiv((unsigned)a2.tilesY);
     a2.nwg_total = (int)nitems;
-    a2.ablate = 0;
-#ifdef ADN_EXPERIMENTS
-    { const char *ab = std::getenv("ADN_C16_ABLATE"); a2.ablate = ab ? std::atoi(ab) : 0; }
-#endif
     static std::atomic<int> cus{0};                   // (one device model per process: gfx950 only, checked at handle creation)
     int c = cus.load(std::memory_order_relaxed);
     int dev = 0;
@@ -647,32 +593,6 @@ hipError_t launch_c16(const ConvArgs &a, hipStream_t st)
         if (e != hipSuccess) return e;
         attr_mask.fetch_or(bit, std::memory_order_release);
     }
-#ifdef ADN_EXPERIMENTS
-    static const bool timeline = std::getenv("ADN_C16_TIMELINE") != nullptr;
-    if (timeline) {
-        const size_t bytes = (size_t)grid * 8 * 8 * sizeof(unsigned long long);
-        if (hipMalloc(&a2.dbg, bytes) != hipSuccess) return hipErrorOutOfMemory;
-        (void)hipMemset(a2.dbg, 0, bytes);
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C16_NT), L::BYTES, st, a2);
-        (void)hipStreamSynchronize(st);
-        std::vector<unsigned long long> hb(bytes / 8);
-        (void)hipMemcpy(hb.data(), a2.dbg, bytes, hipMemcpyDeviceToHost);
-        (void)hipFree(a2.dbg);
-        double sum[3] = {0, 0, 0}, steps = 0, span = 0, byw[8][3] = {};
-        for (long b = 0; b < grid * 8; ++b) {
-            for (int k = 0; k < 3; ++k) { sum[k] += (double)hb[b * 8 + k]; byw[b & 7][k] += (double)hb[b * 8 + k]; }
-            steps += (double)hb[b * 8 + 3];
-            span += (double)hb[b * 8 + 4];
-        }
-        if (steps < 1) steps = 1;
-        std::fprintf(stderr, "[c16 timeline EPI %d WRES %d] H %d W %d Cin %d Cout %d nchunk %d: per step and wave: issue + MFMAs %.0f  copies awaited %.0f  "
-                             "barrier %.0f  (sum %.0f clocks; ideal 4608);  by wave (issue / wait / barrier):", EPI, (int)WRES, a2.H, a2.W,
-                     a2.s0.C + a2.s1.C, a2.Cout, a2.nchunk, sum[0] / steps, sum[1] / steps, sum[2] / steps, span / steps);
-        for (int w = 0; w < 8; ++w) std::fprintf(stderr, " w%d %.0f/%.0f/%.0f", w, byw[w][0] / steps * 8, byw[w][1] / steps * 8, byw[w][2] / steps * 8);
-        std::fprintf(stderr, "\n");
-        return hipGetLastError();
-    }
-#endif
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C16_NT), L::BYTES, st, a2);
     return hipGetLastError();
 }

@@ -903,15 +903,6 @@ hipError_t launch_dma_cfg(const ConvArgs &a, hipStream_t st)
     return hipGetLastError();
 }
 
-#ifdef ADN_EXPERIMENTS
-// true: register-staged kernels everywhere (A/B runs of an experiments build only)
-inline bool staging_regs()
-{
-    static const bool regs = []() { const char *e = std::getenv("ADN_CONV_STAGING"); return e && e[0] == 'r'; }();
-    return regs;
-}
-#endif
-
 template <typename T>
 hipError_t launch_conv_mfma_t(ConvKind kind, const ConvArgs &a, hipStream_t st)
 {
@@ -919,20 +910,7 @@ hipError_t launch_conv_mfma_t(ConvKind kind, const ConvArgs &a, hipStream_t st)
         // fp16: the matrix cores are 16x faster than for fp32 while the CU's ingest path is not, so the kernel is
         // bound by the bytes staged per FLOP: LDS-DMA staging, and 8-wave workgroups on 32x16-pixel tiles x 64 couts
         // (132 staged bytes per MFMA; 16x16 px x 128 couts would be 164), two workgroups per CU.
-        // (the register-staged conv_mfma<_Float16, ...> instances exist in experiments builds only: A/B runs)
-        if (kind == CONVT2X2) {
-#ifdef ADN_EXPERIMENTS
-            if (staging_regs()) return launch_cfg<T, 8, 128, 2, 2, 1, CONVT_KG, CONVT2X2>(a, st);
-#endif
-            return launch_dma_cfg<T, 8, 128, 2, 2, 1, CONVT_KG, CONVT2X2, CONVT_WPE>(a, st);
-        }
-#ifdef ADN_EXPERIMENTS
-        if (staging_regs()) {
-            if (kind == CONV3X3_RELU_DOT) return hipErrorInvalidValue;
-            if (kind == CONV3X3_RELU_POOL) return launch_cfg<T, 32, 64, 8, 1, 9, 1, CONV3X3_RELU_POOL>(a, st);
-            return launch_cfg<T, 32, 64, 8, 1, 9, 1, CONV3X3_RELU>(a, st);
-        }
-#endif
+        if (kind == CONVT2X2) return launch_dma_cfg<T, 8, 128, 2, 2, 1, CONVT_KG, CONVT2X2, CONVT_WPE>(a, st);
         if (kind == CONV3X3_RELU_DOT) {
             if (a.nct != 1 || !a.dotw || !a.dot_out) return hipErrorInvalidValue;      // needs all couts in one workgroup
             return launch_dma_cfg<T, 32, 64, 8, 1, 9, 1, CONV3X3_RELU_DOT, 4>(a, st);
@@ -942,12 +920,6 @@ hipError_t launch_conv_mfma_t(ConvKind kind, const ConvArgs &a, hipStream_t st)
     } else {
         if (kind == CONV3X3_RELU_DOT) return hipErrorInvalidValue;     // fp32: only the Winograd kernel fuses the last layer
         if (kind == CONVT2X2) {
-#ifdef ADN_EXPERIMENTS
-            if (staging_regs()) {
-                if (a.split) return hipErrorInvalidValue;      // the register-staged kernel reads fp32-packed weights: create the handle with ADN_CONVT_SPLIT=0
-                return launch_cfg<T, 8, 128, 2, 2, 1, CONVT_KG, CONVT2X2>(a, st);
-            }
-#endif
             // a.split: weights packed as three bf16 planes (pack_convt_split): the split-bf16 form on the bf16 matrix cores
             if (a.split) return launch_dma_cfg<T, 8, 128, 2, 2, 1, CONVT_KG, CONVT2X2, 3, 1>(a, st);
             return launch_dma_cfg<T, 8, 128, 2, 2, 1, CONVT_KG, CONVT2X2, CONVT_WPE>(a, st);

@@ -374,14 +374,8 @@ template <int M, int NW, int FPB, int WPE, bool FIT>
 __global__ __launch_bounds__(NW * 64, WPE) void stft_wave_kernel(const float *__restrict__ audio, long L, int hop, int pad,
                                                              long n_frames, int groups_per_clip, int gpb,
                                                              int blocks_per_clip, const float *__restrict__ tables,
-                                                             float *__restrict__ out, int ablate_arg, const StftOut o)
+                                                             float *__restrict__ out, const StftOut o)
 {
-#ifdef ADN_EXPERIMENTS
-    const int ablate = ablate_arg;              // timing experiments (ADN_STFT_ABLATE): skip loads (1) / stores (2) / FFT passes (4)
-#else
-    constexpr int ablate = 0;
-    (void)ablate_arg;
-#endif
     constexpr int N = 2 * M, TPF = M / 8, NT = NW * 64;
     constexpr int SLOTS = NT / TPF, FPS = FPB / SLOTS;      // frames per slot and group, processed in sequence
     constexpr int MAGSTR = FPB + 1;
@@ -416,10 +410,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void stft_wave_kernel(const float *__
     auto load_frame = [&](int fidx, v2f *dst) {
         const int fstart = fidx * hop - pad;               // may be < 0 (centre padding) or run past the clip
         const float *ap = aud + fstart + 2 * t;
-        if (ablate & 1) {                                  // timing experiment only: no audio traffic
-#pragma unroll
-            for (int u = 0; u < 8; ++u) dst[u] = v2f{(float)(fidx + u), 1.f};
-        } else if (fstart >= 0 && fstart + N <= Li && base_aligned && !(fstart & 1)) {
+        if (fstart >= 0 && fstart + N <= Li && base_aligned && !(fstart & 1)) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) dst[u] = *reinterpret_cast<const v2f *>(ap + 2 * u * TPF);
         } else {
@@ -482,7 +473,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void stft_wave_kernel(const float *__
             // hop = n_fft/4 (the reference's and BASELINE's setting): the next frame of this slot starts 2*TPF
             // complex points later, i.e. its element u is this frame's element u+2 -> shift six registers and load
             // two (each audio sample is read once instead of four times)
-            if (hop * 4 == N && fn != 0 && fs >= 0 && fs + N <= Li && base_aligned && !(fs & 1) && !(ablate & 1)) {
+            if (hop * 4 == N && fn != 0 && fs >= 0 && fs + N <= Li && base_aligned && !(fs & 1)) {
 #pragma unroll
                 for (int u = 0; u < 6; ++u) nx[u] = nx[u + 2];
                 const float *ap = aud + fs + 2 * t;
@@ -493,7 +484,6 @@ __global__ __launch_bounds__(NW * 64, WPE) void stft_wave_kernel(const float *__
             }
         }
 
-        if (!(ablate & 4)) {                   // (4: timing experiment -- the three FFT passes skipped, everything else kept)
         // pass 1: radix 8, P = 1
         vdft<8>(v);
 #pragma unroll
@@ -501,10 +491,6 @@ __global__ __launch_bounds__(NW * 64, WPE) void stft_wave_kernel(const float *__
         wave_lds_fence();
         wave_pass<M, R2, 8, 1, (R3 > 1 ? 2 : 3)>(sc, tw2, t, v);
         if constexpr (R3 > 1) wave_pass<M, R3, 8 * R2, 2, 3>(sc, tw3, t, v);
-        } else {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) asm volatile("" ::"v"(v[q]));
-        }
 
         // ---- real-FFT post-processing + magnitude into the [bin][frame] image ----
         float *mg = s_mag + fcol;
@@ -551,19 +537,18 @@ __global__ __launch_bounds__(NW * 64, WPE) void stft_wave_kernel(const float *__
 #pragma unroll
                         for (int j = 0; j < SUB; ++j) {
                             const int kk = 32 * blk + HALF * j;         // compile-time part of the row index
-                            if ((ablate & 2) && kk > 0) break;          // timing experiment: one row block only
                             if ((kk + 31 <= M || kk + krow0 <= M) && (!FIT || kk + krow0 < out_rows))
                                 (gbase + (long)kk * row_stride)[voff] = FIT ? stft_emit(mp0[kk * MAGSTR], o.quantize) : mp0[kk * MAGSTR];
                         }
                 }
             } else {
-                if (fglob < n_frames && !((ablate & 2) && rid > 0)) {
+                if (fglob < n_frames) {
                     float *op = oclip + (long)rid * row_stride + fglob;
                     const float *mp = s_mag + rid * MAGSTR + fr;
                     const long ostep = (long)ROWS * row_stride;
                     const int kend = M + 1 < out_rows ? M + 1 : out_rows;
 #pragma unroll 4
-                    for (int k = rid; k < ((ablate & 2) ? 1 : kend); k += ROWS) {
+                    for (int k = rid; k < kend; k += ROWS) {
                         *op = FIT ? stft_emit(*mp, o.quantize) : *mp;
                         op += ostep;
                         mp += ROWS * MAGSTR;
@@ -751,16 +736,6 @@ __global__ __launch_bounds__(NW * 64, WPE) void stft_fit_kernel(const float *__r
     }
 }
 
-inline int stft_ablate()
-{
-#ifdef ADN_EXPERIMENTS
-    const char *a = std::getenv("ADN_STFT_ABLATE");
-    return a ? std::atoi(a) : 0;
-#else
-    return 0;
-#endif
-}
-
 template <int M, int NW, int FPB, int WPE = 3>
 hipError_t launch_wave(const float *audio, int n_clips, long L, int hop, int pad, long n_frames, const float *tables,
                        float *out, const StftOut &o, hipStream_t st, int gpb)
@@ -781,7 +756,7 @@ hipError_t launch_wave(const float *audio, int n_clips, long L, int hop, int pad
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(NW * 64), lds, st, audio, L, hop, pad, n_frames, (int)groups,
-                       gpb, (int)bpc, tables, out, stft_ablate(), o);
+                       gpb, (int)bpc, tables, out, o);
     return hipGetLastError();
 }
 
@@ -906,22 +881,8 @@ hipError_t launch_stft_mag(const float *audio, int n_clips, long L, int n_fft, i
     hipError_t e = get_tables(n_fft, &tables, st);
     if (e != hipSuccess) return e;
     const int pad = center ? n_fft / 2 : 0;
-#ifdef ADN_EXPERIMENTS
-    // experiment switches (A/B runs); variant 0 = workgroup-synchronous kernel, unset = default
-    const char *ev = std::getenv("ADN_STFT_VARIANT");
-    const int variant = ev ? std::atoi(ev) : -1;
-    const char *eg = std::getenv("ADN_STFT_GPB");
-    const int gpb = eg ? std::atoi(eg) : 1;
-#else
-    constexpr int variant = -1;
     constexpr int gpb = 1;                                // frame groups per workgroup (1 measured best: no in-loop barriers)
-#endif
-#ifdef ADN_EXPERIMENTS
-    static const bool fit_persistent = []() { const char *e = std::getenv("ADN_STFT_FIT_PERSISTENT"); return !e || std::atoi(e) != 0; }();
-#else
-    constexpr bool fit_persistent = true;
-#endif
-    if (quantize && fit_persistent && variant != 0) {          // adn_stft_mag_fit: persistent whole-line kernel (above)
+    if (quantize) {                                       // adn_stft_mag_fit: persistent whole-line kernel (above)
         switch (n_fft) {
             case 256: return launch_fit<128, 4>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st);
             case 512: return launch_fit<256, 4>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st);
@@ -929,39 +890,14 @@ hipError_t launch_stft_mag(const float *audio, int n_clips, long L, int n_fft, i
             default: break;
         }
     }
-    if (variant != 0) {
-        switch (n_fft) {
-            case 64: return launch_wave<32, 1, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st, gpb);
-            case 128: return launch_wave<64, 2, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st, gpb);
-            case 256: return launch_wave<128, 4, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st, gpb);
-            case 512:
-#ifdef ADN_EXPERIMENTS
-                if (variant == 1) return launch_wave<256, 8, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st, gpb);
-                if (variant == 2) return launch_wave<256, 4, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st, gpb);
-                if (variant == 3) return launch_wave<256, 2, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st, gpb);
-                if (variant == 4) return launch_wave<256, 2, 32>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st, gpb);
-#endif
-                // measured on 10 k x 3 s clips (ms): <8,16> 9.31, <4,16> 5.42, <2,32> 6.08, <2,16> 4.78, <4,32> 4.71
-                return launch_wave<256, 4, 32>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st, gpb);
-            case 1024:
-#ifdef ADN_EXPERIMENTS
-                if (variant == 1) return launch_wave<512, 8, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st, gpb);
-                if (variant == 3) return launch_wave<512, 8, 32>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st, gpb);
-                if (variant == 4) return launch_wave<512, 4, 32>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st, gpb);
-                if (variant == 5) return launch_wave<512, 8, 16, 4>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st, gpb);
-#endif
-                return launch_wave<512, 4, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st, gpb);
-            default: break;
-        }
-    }
-    switch (n_fft) {
-#ifdef ADN_EXPERIMENTS                  // n_fft <= 1024 reaches the workgroup-synchronous kernel only with ADN_STFT_VARIANT=0 (A/B runs)
-        case 64: return launch_m<32>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st);
-        case 128: return launch_m<64>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st);
-        case 256: return launch_m<128>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st);
-        case 512: return launch_m<256>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st);
-        case 1024: return launch_m<512>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st);
-#endif
+    switch (n_fft) {                                      // a frame fits one wave: the wave-synchronous kernel
+        case 64: return launch_wave<32, 1, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st, gpb);
+        case 128: return launch_wave<64, 2, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st, gpb);
+        case 256: return launch_wave<128, 4, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st, gpb);
+        // <waves, frames per group>, measured on 10 k x 3 s clips (ms): <8,16> 9.31, <4,16> 5.42, <2,32> 6.08, <2,16> 4.78, <4,32> 4.71
+        case 512: return launch_wave<256, 4, 32>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st, gpb);
+        case 1024: return launch_wave<512, 4, 16>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st, gpb);
+        // larger transforms: the workgroup-synchronous kernel
         case 2048: return launch_m<1024>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st);
         case 4096: return launch_m<2048>(audio, n_clips, L, hop, pad, n_frames, tables, out, o, st);
         default: return hipErrorInvalidValue;

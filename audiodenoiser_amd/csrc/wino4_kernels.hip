@@ -871,7 +871,6 @@ hipError_t launch_wino4_conv(ConvKind kind, const ConvArgs &a, hipStream_t st)
     }
     a2.nwg_total = (int)nwg;
     const long grid = nwg;
-    a2.ablate = 0;
     static std::atomic<unsigned long long> attr_mask{0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;

@@ -270,24 +270,6 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
     }
     const int b_lane = (q * 16 + ti) * 4;                    // U slab [pos/2][j][q][n%16][pos%2][2]
 
-    // diagnostic stamps (p.dbg != nullptr only; never in production): cycles per phase, summed over the chunks
-#if defined(ADN_EXPERIMENTS) && defined(ADN_WINO_STAMPS)
-    const bool stamp = p.dbg != nullptr;
-#else
-    constexpr bool stamp = false;                     // -DADN_EXPERIMENTS -DADN_WINO_STAMPS: in-kernel phase stamps
-#endif
-    unsigned long long tprev = 0, tsum[6] = {0, 0, 0, 0, 0, 0};
-#define ADN_STAMP(k)                                                                         \
-    do {                                                                                     \
-        if (stamp) {                                                                         \
-            unsigned long long t_;                                                           \
-            __builtin_amdgcn_sched_barrier(0);                                               \
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");       \
-            __builtin_amdgcn_sched_barrier(0);                                               \
-            tsum[k] += t_ - tprev;                                                           \
-            tprev = t_;                                                                      \
-        }                                                                                    \
-    } while (0)
     if constexpr (SRC == 1) {
         // input window (zero outside the image: the FIRST convolution's padding) and first-layer weights -> LDS
         const float *xin = static_cast<const float *>(p.s0.ptr) + (size_t)n * p.H * p.W;
@@ -306,21 +288,13 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
     ADN_DMA_END();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (stamp) {
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
-    }
     for (int c = 0; c < nloc; ++c) {                  // c counts this workgroup's chunks; the layer's chunk is c0 + c
         // the copy of chunk c+1 is issued in four slices between the MFMA groups below: a wave stalled in VMEM issue
         // (back-pressure of the CU's ~12 B/clk ingest path) then overlaps its SIMD partner's MFMAs instead of
         // delaying its own
-#ifdef ADN_EXPERIMENTS
-        const bool more = c + 1 < nloc && !((p.ablate & 1) && c >= 1);   // ablate&1: timing experiment, no copies
-#else
         const bool more = c + 1 < nloc;
-#endif
         const int nb = (c + 1) & 1;
         if (more) ADN_DMA_BEGIN(c0 + c + 1);
-        ADN_STAMP(0);
         const float *sA = smem + (c & 1) * DBUF;
         const float *sB = sA + HR * NT * 4;
         f32x2 d[4][4];
@@ -328,7 +302,6 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int b = 0; b < 4; ++b) d[a][b] = *(lds_cv_f32x2 *)(sA + a_lane[b] + a * DROW);
-        ADN_STAMP(1);                                     // patch reads landed
         f32x2 t[4][4];
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
@@ -364,7 +337,6 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
         _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                   \
             acc[j][4 * (g) + s] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[4 * (g) + s].y, src[j][s].y, acc[j][4 * (g) + s], 0, 0, 0)
 #define ADN_LANDED(x) asm volatile("" ::"v"(x[1][3].y))
-        ADN_STAMP(2);                                     // transform
         ADN_LOADU(ua, 0);
         __builtin_amdgcn_sched_barrier(0);
         ADN_LANDED(ua);
@@ -409,24 +381,14 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
 #undef ADN_LANDED
 #undef ADN_LOADU
 #undef ADN_MFMAS
-        ADN_STAMP(3);                                     // B reads + 64 MFMAs issued
         // every wave: its own DMA writes have landed (vmcnt) ; then all waves: image c is free, image c+1 complete
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        ADN_STAMP(4);                                     // own DMA landed
         __syncthreads();
-        ADN_STAMP(5);                                     // barrier
     }
 #undef ADN_DMA
 #undef ADN_DMA_BEGIN
 #undef ADN_DMA_PIECE
 #undef ADN_DMA_END
-#undef ADN_STAMP
-    if (stamp && lane == 0) {
-        unsigned long long *o = reinterpret_cast<unsigned long long *>(p.dbg) + ((size_t)blockIdx.x * NW + wave) * 8;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) o[k] = tsum[k];
-        o[6] = (unsigned long long)nloc;
-    }
 
     if constexpr (EPI == CONV3X3_RELU_DOT) {
         // Fused last layer: out[px] += sum over this workgroup's 32 couts of w1x1[c] * ReLU(conv[c][px] + bias[c]).
@@ -568,10 +530,6 @@ hipError_t launch_wino_dma_n(ConvKind kind, const ConvArgs &a, hipStream_t st)
     const long ptiles = (long)a2.N * a2.tilesY * a2.tilesX;
     const long nwg = ((ptiles + gp - 1) / gp) * gp * a2.nct;
     if (nwg <= 0 || nwg > 0x7fffffffL) return hipErrorInvalidValue;
-    a2.ablate = 0;
-#ifdef ADN_EXPERIMENTS
-    { const char *ab = std::getenv("ADN_WINO_ABLATE"); a2.ablate = ab ? std::atoi(ab) : 0; }   // timing experiments only
-#endif
     // the attribute is per device: remember which devices of this process have it (one process per GPU is the
     // deployment model, but a handle may be created on any device)
     static std::atomic<unsigned long long> attr_mask{0};
@@ -594,17 +552,6 @@ hipError_t launch_wino_dma_n(ConvKind kind, const ConvArgs &a, hipStream_t st)
             if (e1 != hipSuccess) return e1;
         }
         attr_mask.fetch_or(bit, std::memory_order_release);
-    }
-    a2.dbg = nullptr;
-#ifdef ADN_EXPERIMENTS
-    const bool stamp = std::getenv("ADN_WINO_STAMP") != nullptr;      // diagnostic path only
-#else
-    constexpr bool stamp = false;
-#endif
-    const size_t dbg_bytes = (size_t)nwg * NW * 8 * sizeof(unsigned long long);
-    if (stamp) {
-        if (hipMalloc(&a2.dbg, dbg_bytes) != hipSuccess) return hipErrorOutOfMemory;
-        (void)hipMemsetAsync(a2.dbg, 0, dbg_bytes, st);
     }
     hipError_t le;
     if (a2.ksplit > 1 && kind == CONV3X3_RELU_DOT) return hipErrorInvalidValue;      // the fused layer is never split
@@ -658,22 +605,6 @@ hipError_t launch_wino_dma_n(ConvKind kind, const ConvArgs &a, hipStream_t st)
     else
         hipLaunchKernelGGL((wino_conv_dma_f32<CONV3X3_RELU, NW, 0>), dim3((unsigned)nwg), dim3(64 * NW), lds, st, a2);
     le = hipGetLastError();
-    if (stamp) {
-        std::vector<unsigned long long> hbuf(dbg_bytes / 8);
-        (void)hipStreamSynchronize(st);
-        (void)hipMemcpy(hbuf.data(), a2.dbg, dbg_bytes, hipMemcpyDeviceToHost);
-        (void)hipFree(a2.dbg);
-        double sum[6] = {0, 0, 0, 0, 0, 0};
-        double chunks = 0;
-        for (long b = 0; b < nwg * NW; ++b) {
-            for (int k = 0; k < 6; ++k) sum[k] += (double)hbuf[b * 8 + k];
-            chunks += (double)hbuf[b * 8 + 6];
-        }
-        if (chunks < 1) chunks = 1;
-        std::fprintf(stderr, "[wino stamp NW=%d] cycles per chunk per wave: dma_issue %.0f  patch_wait %.0f  transform %.0f  "
-                             "mfma %.0f  dma_wait %.0f  barrier %.0f\n", NW, sum[0] / chunks, sum[1] / chunks,
-                     sum[2] / chunks, sum[3] / chunks, sum[4] / chunks, sum[5] / chunks);
-    }
     return le;
 }
 
@@ -690,12 +621,8 @@ long wino_workgroups(const ConvArgs &a)
 
 hipError_t launch_wino_conv(ConvKind kind, const ConvArgs &a, hipStream_t st)
 {
-#ifdef ADN_EXPERIMENTS
-    // experiment switch ADN_WINO_WAVES=8: one 8-wave workgroup per CU on a 16x32 px tile (fewer staged bytes per
-    // MFMA, but measured slower: 197 vs 232 TFLOP/s, its two waves per SIMD run in lockstep)
-    static const int waves = []() { const char *e = std::getenv("ADN_WINO_WAVES"); return e ? std::atoi(e) : 4; }();
-    if (waves == 8) return launch_wino_dma_n<8>(kind, a, st);
-#endif
+    // (an 8-wave workgroup per CU on a 16x32-pixel tile -- DmaGeom<8>: fewer staged bytes per MFMA -- measured slower, 197 vs
+    // 232 TFLOP/s: its two waves per SIMD run in lockstep)
     return launch_wino_dma_n<4>(kind, a, st);
 }
 

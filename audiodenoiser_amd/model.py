@@ -89,6 +89,19 @@ class UNet(nn.Module):
         self._handle_key = None
         self._workspace = None
         self._compute_dtype = "f32"
+        self._batch_invariant = None                  # None: the library's default (adn.h, adn_unet_set_batch_invariant)
+
+    # ------------------------------------------------------------------ kernel choice
+    def set_batch_invariant(self, on: bool = True):
+        """fp32 path.  Default (off): the library picks the kernel of each 3x3 layer by the launch's grid -- fastest at every batch
+        size, but the same clip computed alone (e.g. the short last batch of a dataset, ``test.py``'s 5-clip set) and inside a large
+        batch then differs in the last bits (<= 2e-5 of max|y|; both within 1e-4 of the reference).  ``set_batch_invariant(True)``
+        pins one kernel per layer by geometry alone: a clip's output is bit-identical whatever batch it is computed in -- use it for
+        evaluation / regression runs that compare outputs across batch sizes (costs up to 2x at batch 1-4)."""
+        self._batch_invariant = bool(on)
+        if self._handle is not None:
+            _lib.check(_lib.load().adn_unet_set_batch_invariant(self._handle, int(self._batch_invariant)), "adn_unet_set_batch_invariant")
+        return self
 
     # ------------------------------------------------------------------ arithmetic type
     def set_compute_dtype(self, dtype: str):
@@ -149,6 +162,8 @@ class UNet(nn.Module):
                        "adn_unet_create_general")
         self._handle = handle
         self._handle_key = key
+        if self._batch_invariant is not None:
+            _lib.check(L.adn_unet_set_batch_invariant(handle, int(self._batch_invariant)), "adn_unet_set_batch_invariant")
         return handle
 
     def _workspace_for(self, n, f, t, device):
@@ -178,6 +193,9 @@ class UNet(nn.Module):
             raise TypeError("expected float32 input")
 
     def forward(self, x: torch.Tensor, return_taps: bool = False):
+        """``(N, C, F, T) float32 -> (N, K, F, T) float32`` (reference ``model.py:70-94``), eval-mode semantics.  Non-finite input
+        values travel as through the reference's ``nn.ReLU`` / ``nn.MaxPool2d`` (NaN-propagating).  Results are within 1e-4 of
+        the reference; they are bit-identical across batch sizes only after :meth:`set_batch_invariant`."""
         self._check_input(x)
         home = x.device
         if not x.is_cuda:

@@ -701,7 +701,7 @@ def main() -> None:
     ap.add_argument("--b256-steps", type=int, default=10)
     ap.add_argument("--no-stft-cpu", action="store_true", help="skip the C-oracle STFT timing inside the stft sub-benchmark")
     ap.add_argument("--no-finite-check", action="store_true",
-                    help="timing experiments of an ADN_BUILD_EXPERIMENTS library only (ablated kernels produce garbage)")
+                    help="skip the finite-output assertion (work-in-progress kernels)")
     ap.add_argument("--dtype", choices=("f32", "f16"), default="f32",
                     help="f32 = headline metric (default); f16 = run the MAIN loop on the fp16 path (BASELINE configs[4])")
     args = ap.parse_args()

@@ -32,7 +32,7 @@
 
 #include <stddef.h>
 
-/* The 27 functions below are the ONLY symbols libadn.so exports: the library is built with -fvisibility=hidden and linked with
+/* The 28 functions below are the ONLY symbols libadn.so exports: the library is built with -fvisibility=hidden and linked with
  * a version script (audiodenoiser_amd/csrc/libadn.map: `adn_*` global, everything else local). */
 #if defined(__GNUC__)
 #define ADN_API __attribute__((visibility("default")))
@@ -92,6 +92,13 @@ ADN_API int adn_unet_create_ex(adn_unet **handle, int device, const float *const
 ADN_API int adn_unet_create_general(adn_unet **handle, int device, const float *const *host_tensors, int n_tensors, int dtype,
                             int in_channels, int num_classes);
 ADN_API int adn_unet_channels(const adn_unet *handle, int *in_channels, int *num_classes);
+/* Kernel choice of the fp32 3x3 layers.  Default (on = 0): per launch, by the launch's grid -- F(4x4,3x3) where its 32x32-pixel
+ * tiles fill the chip, F(2x2,3x3) (cut along K where even that grid is too small) otherwise: fastest at every batch size, but the
+ * same clip computed alone and inside a large batch then differs in the last bits (both within 1e-4 of the reference).
+ * on = 1: one kernel per layer chosen by the layer's geometry alone -- a clip's result is bit-identical whatever batch it is
+ * computed in (evaluation / regression runs that compare across batch sizes).  May be changed between forwards.  Initial value:
+ * 0, or the environment's ADN_BATCH_INVARIANT when the handle is created.  No effect on an fp16 handle (one kernel per layer). */
+ADN_API int adn_unet_set_batch_invariant(adn_unet *handle, int on);
 ADN_API int adn_unet_destroy(adn_unet *handle);
 
 /* Bytes of device scratch adn_unet_forward needs for an (N,1,F,T) batch (half as much for an fp16 handle;
@@ -176,6 +183,22 @@ ADN_API int adn_stft_complex(const float *audio, int n_clips, long length, int n
 ADN_API int adn_istft_workspace_bytes(int n_clips, int n_frames, int n_fft, size_t *bytes);
 ADN_API int adn_istft(const float *spec, int n_clips, int n_frames, int n_fft, int hop, void *workspace, size_t workspace_bytes,
               float *audio_out, void *stream);
+
+/* ---- environment switches -------------------------------------------------------------------------------------------------
+ * Read ONCE, when a U-Net handle is created (never per call).  None is needed in production: the defaults are the measured best
+ * and every family below is covered by the parity tests (tests/test_gpu_variants.py::MODES).  They select between kernel
+ * families that all compute the reference's forward within the stated tolerance:
+ *
+ *   ADN_CONV_ALGO=direct     fp32 3x3 layers on the direct implicit-GEMM kernels (conv_mfma) instead of Winograd
+ *   ADN_WINO_TILE=2 | 4      fp32: F(2x2,3x3) for every 3x3 layer | F(4x4,3x3) for every plain / pooled 3x3 layer whatever its size
+ *   ADN_WINO_SPLITK=1        fp32: split-K wherever the F(2x2,3x3) grid cannot fill the chip (default: only by the small-grid rule)
+ *   ADN_BATCH_INVARIANT=1    initial value of adn_unet_set_batch_invariant (above)
+ *   ADN_AUTO_GRID=n, ADN_AUTO_GRID64=n   thresholds of the small-grid rule in F(4x4,3x3) workgroups (192 / 512; tools/small_grid_probe.py)
+ *   ADN_CONVT_SPLIT=0        fp32 transposed convolutions on the exact-fp32 MFMA instead of the three-term bf16 split
+ *   ADN_F16_CONV=32          fp16 3x3 layers on conv_dma<_Float16> (32x32x16 MFMA) instead of conv16_f16 (16x16x32)
+ *   ADN_F16_FIRST=0          fp16: Conv2d(1 -> 64) as its own launch instead of fused into down1's second convolution
+ *
+ * The library reads no other environment variable; its sources contain no timing-experiment code. */
 
 #ifdef __cplusplus
 }

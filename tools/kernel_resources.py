@@ -2,7 +2,7 @@
 """Per-kernel register / scratch / occupancy table of one csrc/*.hip translation unit, from hipcc's
 -Rpass-analysis=kernel-resource-usage remarks (no GPU needed: cross-compiles for gfx950).
 
-    python tools/kernel_resources.py audiodenoiser_amd/csrc/conv_kernels.hip [-DADN_EXPERIMENTS ...]
+    python tools/kernel_resources.py audiodenoiser_amd/csrc/conv_kernels.hip [-D...]
 """
 import os
 import re
