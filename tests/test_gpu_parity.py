@@ -113,7 +113,8 @@ def test_unet_full_size_batch64(net, net_invariant, dev, weights_np):
         net.set_batch_invariant(True)
         assert torch.equal(net(x[37:38].clone())[0], y[37])
         net.set_batch_invariant(False)
-        assert torch.equal(net(x[37:38].clone()), yi if i == 37 else net(x[37:38].clone()))
+        y37 = net(x[37:38].clone())                      # back on the small-grid kernels: last-bit differences again, deterministic
+        assert torch.equal(y37, net(x[37:38].clone())) and float((y37[0] - y[37]).abs().max()) <= 2e-5 * float(y[37].abs().max())
         # (2) batch order equivariance, bit exact
         perm = torch.randperm(n, generator=torch.Generator().manual_seed(1)).to(dev)
         assert torch.equal(net(x[perm].contiguous()), y[perm])
