@@ -327,9 +327,10 @@ struct Plan {
 
 bool make_plan(int N, int F, int T, bool f16, Plan &p)
 {
-    // T <= 4094: the first layer stages 10 rows x (T+2) floats in LDS; F*T*64 elements per image must index in int32
-    // F*T < 2^24: a 64-channel fp32 image stays below 4 GB, the range of the buffer descriptors the copy kernels address it with
-    if (N < 1 || F < 16 || T < 16 || T > 4094 || (long)F * T >= (1L << 24)) return false;
+    // F*T < 2^27: ONE 8-channel block of a full-resolution fp32 image (F*T*32 bytes) stays below 4 GB, the range of a buffer
+    // descriptor -- the copy kernels walk an image block by block with a rebased descriptor, so the image itself (32 GB of fp32 at
+    // that size) may exceed it.  No other limit: the reference's network is fully convolutional (model.py:70-94), any F, T >= 16.
+    if (N < 1 || F < 16 || T < 16 || (long)F * T >= (1L << 27)) return false;
     p.N = N;
     p.H[0] = F;
     p.W[0] = T;
@@ -423,7 +424,7 @@ struct Algo {
 // workgroups of the F(4x4,3x3) launch of a layer (launch_wino4_conv's grid without the supertile padding)
 long wino4_grid(const adn::ConvArgs &a)
 {
-    const int pair = a.W <= 16 ? 1 : 0;
+    const int pair = adn::wino4_pair_mode(a) ? 1 : 0;
     return (long)((a.N + pair) >> pair) * ((a.H + 31) / 32) * ((a.W + 31) / 32) * (a.Cout / 32);
 }
 
@@ -488,15 +489,13 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
 {
     if (!h || !x || !y) return fail(ADN_ERR_INVALID, "adn_unet_forward: null handle/x/y");
     Plan p;
-    if (!make_plan(N, F, T, h->f16, p)) return fail(ADN_ERR_INVALID, "adn_unet_forward: need N>=1, F,T>=16, T<=4094 and F*T<2^24");
+    if (!make_plan(N, F, T, h->f16, p)) return fail(ADN_ERR_INVALID, "adn_unet_forward: need N>=1, F,T>=16 and F*T<2^27");
     if (!workspace || ws_bytes < p.total)
         return fail(ADN_ERR_WORKSPACE, "adn_unet_forward: workspace too small (see adn_unet_workspace_bytes)");
     // the activation buffers are carved out of the workspace in 256-byte granules and read with 16-byte LDS-DMA /
     // b128 accesses; x and y are accessed as single floats
     if (!aligned_to(workspace, 16)) return fail(ADN_ERR_INVALID, "adn_unet_forward: workspace must be 16-byte aligned");
     if (!aligned_to(x, 4) || !aligned_to(y, 4)) return fail(ADN_ERR_INVALID, "adn_unet_forward: x and y must be 4-byte aligned");
-    if ((long)h->in_ch * (T + 2) > 4096)
-        return fail(ADN_ERR_INVALID, "adn_unet_forward: in_channels * (T + 2) must be <= 4096 (the first layer stages its input window on chip)");
     DeviceGuard guard(h->device);
     if (guard.err != hipSuccess) return fail_hip(guard.err, "hipSetDevice");
 
@@ -530,7 +529,13 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
         if (algo.f4 || algo.ksplit > 1) fused_first = false;
     }
     // fp16 path: the first layer is computed inside conv16_f16's halo stage of down1's second conv (conv16_kernels.hip, FIRST)
-    if (f16 && h->f16_conv != 0 && h->f16_fuse_first && h->c3[0].w16_off && h->in_ch == 1) fused_first = true;
+    // (... where conv16_f16 takes the layer at all: conv16_applicable refuses images beyond its 32-bit offsets)
+    if (f16 && h->f16_conv != 0 && h->f16_fuse_first && h->c3[0].w16_off && h->in_ch == 1) {
+        adn::ConvArgs probe = conv_args(h, h->c3[0], adn::CONV3X3_RELU_POOL, x, 1, nullptr, 0, 0, 0, tA, tA, N, p.H[0], p.W[0]);
+        probe.firstw = h->dev + h->first_w;
+        probe.firstb = h->dev + h->first_b;
+        fused_first = adn::conv16_applicable(adn::CONV3X3_RELU_POOL, probe);
+    }
     ADN_MARK();
     if (!fused_first)
         ADN_HIP(adn::launch_conv_first(x, h->dev + h->first_w, h->dev + h->first_b, tA, f16, N, p.H[0], p.W[0], h->in_ch, st));
@@ -918,7 +923,7 @@ int adn_unet_workspace_bytes(const adn_unet *h, int N, int F, int T, size_t *byt
 {
     if (!bytes) return fail(ADN_ERR_INVALID, "adn_unet_workspace_bytes: null");
     Plan p;
-    if (!make_plan(N, F, T, h ? h->f16 : false, p)) return fail(ADN_ERR_INVALID, "adn_unet_workspace_bytes: need N>=1, F,T>=16, T<=4094 and F*T<2^24");
+    if (!make_plan(N, F, T, h ? h->f16 : false, p)) return fail(ADN_ERR_INVALID, "adn_unet_workspace_bytes: need N>=1, F,T>=16 and F*T<2^27");
     *bytes = p.total;
     return ADN_OK;
 }
@@ -1006,7 +1011,7 @@ int adn_per_clip_l1(const float *a, const float *b, int n_clips, long elems_per_
 int adn_perceptual_loss_workspace_bytes(int n_clips, int F, int T, size_t *bytes)
 {
     if (!bytes || n_clips < 1 || F < 1 || T < adn::ADN_LOSS_MIN_T || T > adn::ADN_LOSS_MAX_T)
-        return fail(ADN_ERR_INVALID, "adn_perceptual_loss_workspace_bytes: need n_clips,F >= 1 and 32 <= T <= 6784");
+        return fail(ADN_ERR_INVALID, "adn_perceptual_loss_workspace_bytes: need n_clips,F >= 1 and 32 <= T < 2^24");
     *bytes = adn::perceptual_loss_workspace_floats(n_clips, F, T) * sizeof(float);
     return ADN_OK;
 }
@@ -1019,9 +1024,8 @@ int adn_perceptual_loss(const float *pred, const float *target, int n_clips, int
     // below that too: loss.py:39-41 with pad_mode "reflect")
     if (n_clips < 1 || F < 1 || T < adn::ADN_LOSS_MIN_T || T > adn::ADN_LOSS_MAX_T ||
         adn::perceptual_loss_lds_bytes(T) > adn::ADN_LOSS_MAX_LDS)
-        return fail(ADN_ERR_INVALID, "adn_perceptual_loss: need n_clips,F >= 1 and 32 <= T <= 6784 (reflect padding of the mel "
-                                     "term needs T > 31; the per-clip series, trig tables and mel frames of one clip must fit "
-                                     "the 160 KiB LDS of a CU)");
+        return fail(ADN_ERR_INVALID, "adn_perceptual_loss: need n_clips,F >= 1 and 32 <= T < 2^24 (reflect padding of the mel "
+                                     "term needs T > 31)");
     const size_t need = adn::perceptual_loss_workspace_floats(n_clips, F, T) * sizeof(float);
     if (!workspace || workspace_bytes < need) return fail(ADN_ERR_WORKSPACE, "adn_perceptual_loss: workspace too small");
     ADN_LAUNCH(adn::launch_perceptual_loss(pred, target, n_clips, F, T, static_cast<float *>(workspace), out,

@@ -103,6 +103,17 @@ struct ConvArgs {
     const float *firstw, *firstb;
 };
 
+// wino4_conv_f32's pair mode: a workgroup tile holds the same 32 rows of TWO neighbouring clips side by side (images at most 16
+// pixels wide, e.g. the 32x16 bottleneck of a 513x256 input).  Its copies reach both clips through one buffer descriptor, so the
+// image of a clip plus one channel block must stay inside the 4 GB a descriptor spans (always, except for absurdly tall 16-wide
+// images, which then run unpaired or on the F(2x2,3x3) kernel).
+inline bool wino4_pair_mode(const ConvArgs &a)
+{
+    if (a.W > 16) return false;
+    const size_t i0 = (size_t)a.s0.C * a.s0.H * a.s0.W * 4, i1 = (size_t)a.s1.C * a.s1.H * a.s1.W * 4;
+    return (i0 > i1 ? i0 : i1) + (size_t)a.H * a.W * 32 < (size_t)0xfffffff0u;
+}
+
 // Number of K splits for a 3x3 layer launched as `nwg` Winograd workgroups of `nchunk` chunks: only when the grid
 // cannot fill the 512 workgroup slots of the chip (2 per CU) and the K loop is long enough to be worth cutting.
 inline int wino_ksplit(long nwg, int nchunk)
@@ -174,11 +185,12 @@ hipError_t launch_stft_complex(const float *audio, int n_clips, long L, int n_ff
 hipError_t launch_quantize_pad(const float *in, int n, int h, int w, float *out, int H, int W, hipStream_t st);
 hipError_t launch_per_clip_l1(const float *a, const float *b, int n_clips, long elems, float *out, hipStream_t st);
 size_t perceptual_loss_workspace_floats(int n_clips, int F, int T);
-// LDS the finishing kernel needs for T frames; the launch is refused above ADN_LOSS_MAX_LDS (160 KiB per CU minus
-// the kernel's static reduction scratch), i.e. T <= ADN_LOSS_MAX_T
+// LDS the finishing kernel needs for T frames (ADN_LOSS_MAX_LDS: 160 KiB per CU minus the kernel's static reduction scratch):
+// up to ADN_LOSS_LDS_T frames a clip's series and mel spectra are held on chip, longer clips keep the series in the workspace
 size_t perceptual_loss_lds_bytes(int T);
 constexpr size_t ADN_LOSS_MAX_LDS = 160 * 1024 - 64;
-constexpr int ADN_LOSS_MAX_T = 6784;
+constexpr int ADN_LOSS_LDS_T = 6784;
+constexpr int ADN_LOSS_MAX_T = 1 << 24;     // (partial sums and frame indices are 32-bit)
 constexpr int ADN_LOSS_MIN_T = 32;          // loss.py:39-41: the mel transform's reflect padding (31 samples) needs T > 31
 hipError_t launch_perceptual_loss(const float *pred, const float *tgt, int n_clips, int F, int T, float *workspace,
                                   float *out, hipStream_t st);

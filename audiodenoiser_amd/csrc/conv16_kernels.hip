@@ -21,6 +21,7 @@
 // slots) + (streamed weights only) the chunk's slab [tap][cout block][k group][cout % 16][8 halfs] = 36 KB.
 #include "adn_internal.h"
 
+#include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -137,20 +138,21 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
         prow[k] = s < C16_BLK_USED ? row : -1000;
         ppx[k] = (q >> 1) | ((q & 1) << 16);        // pixel, half in bit 16
     }
-    // descriptors are rebuilt from scalars at every use (two SALU operations) instead of being carried through the loop
+    // descriptors are rebuilt from scalars at every use (two SALU operations) instead of being carried through the loop; a halo
+    // descriptor spans ONE channel block (H * W * 32 bytes: < 4 GB for every F * T < 2^27) -- its 64-bit base moves with the chunk,
+    // so an image may exceed the 4 GB one descriptor spans
     const char *hbase = nullptr;                    // image of clip n in the current source
-    unsigned himg_bytes = 0, hblk_bytes = 0;        // bytes of that image / of one of its channel blocks (H * W * 32)
+    unsigned hblk_bytes = 0;                        // bytes of one of its channel blocks (H * W * 32)
     auto plan = [&](const ConvSrc &s, const C16Item &it) {
         const int gy0 = it.ty * C16_TH - 1 - s.offY, gx0 = it.tx * C16_TW - 1 - s.offX;
 #pragma unroll
         for (int k = 0; k < C16_HPIECES; ++k) {
             const int y = gy0 + prow[k], x = gx0 + (ppx[k] & 0xffff);
-            const unsigned off = (unsigned)((y * s.W + x) * 32 + (ppx[k] >> 16) * 16);
+            const unsigned off = (unsigned)(y * s.W + x) * 32u + (unsigned)((ppx[k] >> 16) * 16);
             hcur[k] = (((unsigned)y < (unsigned)s.H) & ((unsigned)x < (unsigned)s.W)) ? off : ADN_DMA_OOB;     // (& not &&: no branches)
         }
-        himg_bytes = (unsigned)(s.C * s.H * s.W) * 2u;
         hblk_bytes = (unsigned)(s.H * s.W) * 32u;
-        hbase = static_cast<const char *>(s.ptr) + (size_t)it.n * himg_bytes;
+        hbase = static_cast<const char *>(s.ptr) + (size_t)it.n * s.C * s.H * s.W * 2;
     };
     if constexpr (!FIRST) plan(p.s0, fi);
     const __amdgpu_buffer_rsrc_t wrs = dma_rsrc(p.wpk, (unsigned)((size_t)p.nct * nchunk * C16_W_SLOTS * 16));
@@ -256,23 +258,23 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
             *reinterpret_cast<u32x2 *>(dst + jb * (C16_BLK_SLOTS * 16)) = hv;
         }
     };
-    auto halo_rsrc = [&]() {
-        const unsigned long long hb = reinterpret_cast<unsigned long long>(hbase);
-        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)hb);
-        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(hb >> 32));
-        return dma_rsrc(reinterpret_cast<const void *>(((unsigned long long)hi << 32) | lo), (unsigned)__builtin_amdgcn_readfirstlane((int)himg_bytes));
-    };
-    // scalar offsets of the fetch step, recomputed when the fetch state moves (fetch_scalars): halo block 0 of the chunk inside
-    // its source, and the chunk's weight slab
-    unsigned hsoff0 = 0, wsoff = 0;
+    // scalars of the fetch step, recomputed when the fetch state moves (fetch_scalars): first channel block of the chunk inside its
+    // source (the two halves of the 64-bit address, wave-uniform by construction), and the chunk's weight slab
+    unsigned hb_lo = 0, hb_hi = 0, wsoff = 0;
     auto fetch_scalars = [&]() {
         const int cl = f_chunk < p.nchunk0 ? f_chunk : f_chunk - p.nchunk0;          // chunk inside the current source
-        hsoff0 = (unsigned)__builtin_amdgcn_readfirstlane(2 * cl * (int)hblk_bytes);
+        const unsigned long long hb = reinterpret_cast<unsigned long long>(hbase) + (unsigned long long)(2 * cl) * hblk_bytes;
+        hb_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)hb);
+        hb_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(hb >> 32));
         wsoff = (unsigned)__builtin_amdgcn_readfirstlane((fi.ct * nchunk + f_chunk) * (C16_W_SLOTS * 16));
     };
+    // descriptor of the chunk's FIRST block; its second block is reached through the scalar offset (which the range check ignores)
+    auto halo_rsrc = [&]() {
+        return dma_rsrc(reinterpret_cast<const void *>(((unsigned long long)hb_hi << 32) | hb_lo), (unsigned)__builtin_amdgcn_readfirstlane((int)hblk_bytes));
+    };
     auto halo_soff = [&](int q) {                   // pieces 0, 1: block 0; 3, 4: block 1; piece 2: waves 0-3 block 0, 4-7 block 1
-        const unsigned h1 = hsoff0 + (unsigned)__builtin_amdgcn_readfirstlane((int)hblk_bytes);
-        return q < 2 ? hsoff0 : q > 2 ? h1 : (wave < 4 ? hsoff0 : h1);
+        const unsigned h1 = (unsigned)__builtin_amdgcn_readfirstlane((int)hblk_bytes);
+        return q < 2 ? 0u : q > 2 ? h1 : (wave < 4 ? 0u : h1);
     };
     // piece q (0 .. NPIECE-1) of the fetch step into image `buf`
     // (`kill`: 0, or ADN_DMA_OOB in the last step of the workgroup -- its copies then fetch nothing: no branch around them)
@@ -464,20 +466,22 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v + p.dot_bias), yrs, off, 0, 0);
                 }
             } else {
+                // output descriptors span ONE channel block (H * W * 32 bytes), based at this item's first block; the four blocks of
+                // the cout tile follow at scalar offsets of one block each (block 3 at 3 * HWb: conv16_applicable admits a layer
+                // only where that stays below 2^32 -- images of up to 44 million pixels; larger ones run on conv_dma<_Float16>)
                 const unsigned HWb = (unsigned)(p.H * p.W) * 32u;          // bytes of one channel block of the output
-                const __amdgpu_buffer_rsrc_t ors = dma_rsrc(static_cast<const char *>(p.out) + (size_t)ci.n * p.Cout * p.H * p.W * 2,
-                                                            (unsigned)(p.Cout * p.H * p.W) * 2u);
+                const __amdgpu_buffer_rsrc_t ors = dma_rsrc(static_cast<const char *>(p.out) + ((size_t)ci.n * p.Cout * p.H * p.W + (size_t)ci.ct * 64 * p.H * p.W) * 2, HWb);
                 const int Hp = p.H >> 1, Wp = p.W >> 1;
                 const unsigned HWpb = (unsigned)(Hp * Wp) * 32u;
-                const __amdgpu_buffer_rsrc_t prs = dma_rsrc(EPI == CONV3X3_RELU_POOL ? static_cast<const char *>(p.pool) + (size_t)ci.n * p.Cout * Hp * Wp * 2 : nullptr,
-                                                            EPI == CONV3X3_RELU_POOL ? (unsigned)(p.Cout * Hp * Wp) * 2u : 0u);
+                const __amdgpu_buffer_rsrc_t prs = dma_rsrc(EPI == CONV3X3_RELU_POOL ? static_cast<const char *>(p.pool) + ((size_t)ci.n * p.Cout * Hp * Wp + (size_t)ci.ct * 64 * Hp * Wp) * 2 : nullptr,
+                                                            EPI == CONV3X3_RELU_POOL ? HWpb : 0u);
                 unsigned ooff[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    ooff[i] = ((gyb + i < p.H) & (gx < p.W)) ? (unsigned)(((gyb + i) * p.W + gx) * 32 + g * 8) : ADN_DMA_OOB;
+                    ooff[i] = ((gyb + i < p.H) & (gx < p.W)) ? (unsigned)((gyb + i) * p.W + gx) * 32u + (unsigned)(g * 8) : ADN_DMA_OOB;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const unsigned cb = (unsigned)__builtin_amdgcn_readfirstlane((ci.ct * 4 + j) * (int)HWb);
+                    const unsigned cb = (unsigned)__builtin_amdgcn_readfirstlane(j * (int)HWb);
                     u32x2 hv[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -488,7 +492,7 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
                         // MaxPool2d(2), floor mode, on the packed halfs (rounding is monotonic: the maximum of the rounded values is the
                         // rounded maximum; v_pk_maximum3_f16: a NaN in the window gives NaN, as nn.MaxPool2d does): rows (2a, 2a+1) are
                         // this lane's row blocks, columns (2x, 2x+1) neighbouring lanes
-                        const unsigned cbp = (unsigned)__builtin_amdgcn_readfirstlane((ci.ct * 4 + j) * (int)HWpb);
+                        const unsigned cbp = (unsigned)__builtin_amdgcn_readfirstlane(j * (int)HWpb);
 #pragma unroll
                         for (int a = 0; a < 2; ++a) {
                             u32x2 m;
@@ -502,7 +506,7 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
                                 m[d] = __builtin_bit_cast(unsigned, __builtin_elementwise_maximum(t, __builtin_bit_cast(f16x2, ou)));
                             }
                             const int py = (gyb >> 1) + a, px = gx >> 1;
-                            const unsigned poff = (!(l16 & 1) & (py < Hp) & (px < Wp)) ? (unsigned)((py * Wp + px) * 32 + g * 8) : ADN_DMA_OOB;
+                            const unsigned poff = (!(l16 & 1) & (py < Hp) & (px < Wp)) ? (unsigned)(py * Wp + px) * 32u + (unsigned)(g * 8) : ADN_DMA_OOB;
                             __builtin_amdgcn_raw_buffer_store_b64(m, prs, poff, cbp, 0);
                         }
                     }
@@ -604,6 +608,13 @@ hipError_t launch_c16(const ConvArgs &a, hipStream_t st)
 bool conv16_applicable(ConvKind kind, const ConvArgs &a)
 {
     if (kind != CONV3X3_RELU && kind != CONV3X3_RELU_POOL && kind != CONV3X3_RELU_DOT) return false;
+    // output blocks are addressed by 32-bit scalar offsets of up to three channel blocks (H * W * 32 bytes each)
+    if ((size_t)a.H * a.W * 96 >= (size_t)0xfffffff0u) return false;
+    {   // the item decode divides by multiply-high with launch constants: exact while item count x divisor < 2^32 (c16_decode)
+        const long ty = (a.H + C16_TH - 1) / C16_TH, tx = (a.W + C16_TW - 1) / C16_TW, nct = a.Cout / 64;
+        const long nitems = (long)a.N * ty * tx * nct, maxd = std::max(nct, std::max(tx, ty));
+        if (nitems <= 0 || nitems > 0x7fffffffL || (unsigned long long)nitems * (unsigned long long)maxd >= 0x100000000ull) return false;
+    }
     if (a.firstw) return kind == CONV3X3_RELU_POOL && a.firstb && a.s0.C == 1 && a.s1.C == 0 && a.Cout == 64;   // fused first layer
     // (an even number of chunks, at least two: the compute side trails the fetch side by one step, and a step's parity fixes its LDS image)
     if ((a.s0.C & 31) || (a.s1.C & 31) || (a.Cout & 63) || ((a.s0.C + a.s1.C) & 63) || a.s0.C + a.s1.C < 64) return false;

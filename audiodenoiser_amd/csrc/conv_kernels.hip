@@ -562,15 +562,15 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void conv_dma(const ConvArgs p)
     }
     const int gy0 = ty * TH - HALO, gx0 = tx * TW - HALO;
 
-    // descriptors: the current source image of clip n (its K-chunks are `cstr` bytes apart) and the weight slabs of this column tile
-    auto src_rsrc = [&](const ConvSrc &s) {
-        return dma_rsrc(static_cast<const T *>(s.ptr) + (size_t)n * s.H * s.W * s.C, (unsigned)((size_t)s.C * s.H * s.W * sizeof(T)));
-    };
-    __amdgpu_buffer_rsrc_t hrs = src_rsrc(p.s0);
+    // descriptors: ONE K-chunk (KG channel blocks, `cstr` bytes: < 4 GB for every image the launcher admits) of the current source
+    // image of clip n -- its 64-bit base walks the image chunk by chunk, so an image may exceed the 4 GB one descriptor spans --
+    // and the weight slabs of this column tile
+    auto src_base = [&](const ConvSrc &s) { return reinterpret_cast<const char *>(static_cast<const T *>(s.ptr) + (size_t)n * s.H * s.W * s.C); };
+    const char *hptr = src_base(p.s0);                  // the next chunk's channel blocks
     const __amdgpu_buffer_rsrc_t wrs = dma_rsrc(static_cast<const float *>(p.wpk) + (size_t)ct * p.nchunk * B_DW,
                                                 (unsigned)((size_t)p.nchunk * B_DW * 4));
     unsigned cstr = (unsigned)((size_t)KG * p.s0.H * p.s0.W * ACT_BLOCK<T> * sizeof(T));
-    unsigned hsoff = 0, wsoff = 0;                      // byte offsets of the next chunk inside the source image / the slabs
+    unsigned wsoff = 0;                                 // byte offset of the next chunk's slab
     const unsigned loff = lane * 16;
     // one wave-instruction of a chunk's copy (slots [k*NT + 64*wave, +64) of image `buf`): halo part or weight part
     unsigned hcur[A_ROUNDS];
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void conv_dma(const ConvArgs p)
         if (sb >= SLOTS) return;                        // tail of the last piece
         float *dst = smem + (size_t)buf * SLOTS * 4 + sb * 4;
         if (k < A_ROUNDS && sb < A_SLOTS) {
-            if (want_a) dma16_buf(hrs, hcur[k < A_ROUNDS ? k : 0], hsoff, dst);
+            if (want_a) dma16_buf(dma_rsrc(hptr, cstr), hcur[k < A_ROUNDS ? k : 0], 0u, dst);
         } else if (want_b) {
             dma16_buf(wrs, loff, wsoff + (unsigned)(sb - A_SLOTS) * 16u, dst);
         }
@@ -608,14 +608,13 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void conv_dma(const ConvArgs p)
     // copy of chunk `c` into image `buf`: NPIECE wave-instructions per thread
     auto dma_chunk = [&](int c, int buf, bool with_b = true) {
         if (c == p.nchunk0) {                          // wave-uniform: switch to the second source (virtual concat)
-            hrs = src_rsrc(p.s1);
-            hsoff = 0;
+            hptr = src_base(p.s1);
             cstr = (unsigned)((size_t)KG * p.s1.H * p.s1.W * ACT_BLOCK<T> * sizeof(T));
             plan(p.s1);
         }
 #pragma unroll
         for (int k = 0; k < NPIECE; ++k) dma_piece(k, buf, true, with_b);
-        hsoff += cstr;
+        hptr += cstr;
         wsoff += B_DW * 4;
     };
 
@@ -718,8 +717,9 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void conv_dma(const ConvArgs p)
 // First layer: Conv2d(1 -> 64, 3x3, pad 1) + folded BN + ReLU (model.py:11-13 via :56).  HBM-bound
 // (4.4 FLOP/B, write-dominated: 64 output floats per input float).  Vector loads queue behind the same CU's
 // outstanding stores (measured with tools/ubench/first_layer.hip: a per-strip global-load form ran at 2.9 TB/s,
-// the same kernel without loads at 5.6), so a workgroup fetches the (FIRST_ROWS+2) x (W+2) input window of its
-// FIRST_ROWS image rows ONCE into LDS and then only stores.  Input is always fp32.
+// the same kernel without loads at 5.6), so a workgroup fetches the (FIRST_ROWS+2) x (cols+2) input window of its
+// FIRST_ROWS x cols pixels ONCE into LDS and then only stores (cols = the whole row width while the window fits the
+// CU's LDS -- up to 4094 frames of one plane --, else the rows are cut into column tiles).  Input is always fp32.
 // ------------------------------------------------------------------------------------------------
 constexpr int FIRST_ROWS = 8;
 
@@ -731,26 +731,30 @@ constexpr int FIRST_ROWS = 8;
 template <typename T>
 __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict__ x, const float *__restrict__ w9x64,
                                                          const float *__restrict__ bias, T *__restrict__ out,
-                                                         int H, int W, int tiles_per_img, int Cin)
+                                                         int H, int W, int tiles_y, int tiles_x, int cols, int Cin)
 {
     constexpr int BE = ACT_BLOCK<T>, NV = BE / 4;  // channels per block, float4 accumulators per block
-    extern __shared__ float s_win[];               // Cin x (FIRST_ROWS+2) rows x (W+2), zero halo
+    extern __shared__ float s_win[];               // Cin x (FIRST_ROWS+2) rows x (cols+2), zero halo
+    const int tiles_per_img = tiles_y * tiles_x;
     const int n = blockIdx.x / tiles_per_img;
-    const int y0 = (blockIdx.x - n * tiles_per_img) * FIRST_ROWS;
-    const int WP = W + 2, PLANE = (FIRST_ROWS + 2) * WP;
-    const float *xp = x + (long)n * Cin * H * W;
+    const int tl = blockIdx.x - n * tiles_per_img;
+    const int ty = tl / tiles_x;
+    const int y0 = ty * FIRST_ROWS, x0 = (tl - ty * tiles_x) * cols;
+    const int cw = min(cols, W - x0);              // pixel columns of this tile
+    const int WP = cw + 2, PLANE = (FIRST_ROWS + 2) * WP;
+    const float *xp = x + (size_t)n * Cin * H * W;
     for (int i = threadIdx.x; i < Cin * PLANE; i += 256) {
         const int ci = i / PLANE, j = i - ci * PLANE;
         const int r = j / WP, c = j - r * WP;
-        const int yy = y0 + r - 1, xx = c - 1;
-        s_win[i] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? xp[((long)ci * H + yy) * W + xx] : 0.f;
+        const int yy = y0 + r - 1, xx = x0 + c - 1;
+        s_win[i] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? xp[((size_t)ci * H + yy) * W + xx] : 0.f;
     }
     __syncthreads();
     const int rows = min(FIRST_ROWS, H - y0);
     const size_t bstr = (size_t)H * W * BE;        // elements between channel blocks
-    for (int i = threadIdx.x; i < rows * W; i += 256) {
-        const int r = i / W, xx = i - r * W;
-        T *op = out + (size_t)n * H * W * 64 + ((size_t)(y0 + r) * W + xx) * BE;
+    for (int i = threadIdx.x; i < rows * cw; i += 256) {
+        const int r = i / cw, xx = i - r * cw;
+        T *op = out + (size_t)n * H * W * 64 + ((size_t)(y0 + r) * W + x0 + xx) * BE;
 #pragma unroll
         for (int b = 0; b < 64 / BE; ++b) {
             f32x4 a[NV];
@@ -953,10 +957,16 @@ hipError_t launch_conv_mfma(ConvKind kind, const ConvArgs &a, bool f16, hipStrea
 hipError_t launch_conv_first(const float *x, const float *w9x64, const float *bias, void *out, bool f16,
                              int N, int H, int W, int Cin, hipStream_t st)
 {
-    const int tpi = (H + FIRST_ROWS - 1) / FIRST_ROWS;
-    const long blocks = (long)N * tpi;
-    const size_t lds = (size_t)Cin * (FIRST_ROWS + 2) * (W + 2) * sizeof(float);
-    if (blocks <= 0 || blocks > 0x7fffffffL || Cin < 1 || lds > 160 * 1024) return hipErrorInvalidValue;   // Cin * (W + 2) <= 4096
+    if (Cin < 1 || Cin > 64) return hipErrorInvalidValue;
+    const int tiles_y = (H + FIRST_ROWS - 1) / FIRST_ROWS;
+    // column tiles: the widest window that fits the CU's LDS, Cin * (cols + 2) <= 4096 floats per window row (whole rows up to
+    // 4094 frames of one plane: one tile, as before); wider images are cut into equal tiles
+    const int max_cols = 4096 / Cin - 2;
+    const int tiles_x = (W + max_cols - 1) / max_cols;
+    const int cols = (W + tiles_x - 1) / tiles_x;
+    const long blocks = (long)N * tiles_y * tiles_x;
+    const size_t lds = (size_t)Cin * (FIRST_ROWS + 2) * (cols + 2) * sizeof(float);
+    if (blocks <= 0 || blocks > 0x7fffffffL || lds > 160 * 1024) return hipErrorInvalidValue;
     if (lds > 64 * 1024) {
         const void *fn = f16 ? reinterpret_cast<const void *>(conv_first_kernel<_Float16>)
                              : reinterpret_cast<const void *>(conv_first_kernel<float>);
@@ -965,10 +975,10 @@ hipError_t launch_conv_first(const float *x, const float *w9x64, const float *bi
     }
     if (f16)
         hipLaunchKernelGGL(conv_first_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), lds, st, x, w9x64, bias,
-                           static_cast<_Float16 *>(out), H, W, tpi, Cin);
+                           static_cast<_Float16 *>(out), H, W, tiles_y, tiles_x, cols, Cin);
     else
         hipLaunchKernelGGL(conv_first_kernel<float>, dim3((unsigned)blocks), dim3(256), lds, st, x, w9x64, bias,
-                           static_cast<float *>(out), H, W, tpi, Cin);
+                           static_cast<float *>(out), H, W, tiles_y, tiles_x, cols, Cin);
     return hipGetLastError();
 }
 

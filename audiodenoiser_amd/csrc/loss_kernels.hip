@@ -65,15 +65,21 @@ __device__ __forceinline__ float block_sum(float v, float *red)
 }
 
 // melfb: [32 freqs][64 mels] fp32 (host, double precision -> float)
+// BIG = false (T <= ADN_LOSS_LDS_T): the clip's two frequency-mean series and the mel power spectra of ALL its frames live in the
+// CU's LDS.  BIG = true (longer clips: the reference's loss has no length limit, loss.py:23-34,60-66): the series live in
+// `series_g` (2 T floats per clip of the workspace, written and read by this workgroup only, L2-resident) and the mel term walks
+// the frames in blocks of LOSS_MEL_FB.
+constexpr int LOSS_MEL_FB = 256;
+template <bool BIG>
 __global__ __launch_bounds__(256) void loss_finish_kernel(const float *__restrict__ partial, int F, int T, int nslab,
-                                                          const float *__restrict__ melfb, float *__restrict__ out)
+                                                          const float *__restrict__ melfb, float *series_g, float *__restrict__ out)
 {
     extern __shared__ float sm[];
-    float *sp = sm, *sq = sm + T;                 // frequency-mean series of pred / target
-    float *tc = sq + T, *ts = tc + 64;            // cos / sin table of the current transform length (<= 63)
-    float *specp = ts + 64;                       // mel: |X|^2 [32][frames], pred then target
-    __shared__ float red[4];
     const long clip = blockIdx.x;
+    float *sp = BIG ? series_g + clip * 2 * (long)T : sm, *sq = sp + T;      // frequency-mean series of pred / target
+    float *tc = BIG ? sm : sq + T, *ts = tc + 64;  // cos / sin table of the current transform length (<= 63)
+    float *specp = ts + 64;                       // mel: |X|^2 [32][frames of a block], pred then target
+    __shared__ float red[4];
     const float *pp = partial + clip * nslab * (long)(2 * T + 1);
     const int tid = threadIdx.x;
 
@@ -127,7 +133,8 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(const float *__restric
 
     // ---- mel: periodic Hann, n_fft 63, hop 16, centred with REFLECT padding, power 2, 32 bins -> 64 mel filters ----
     const int n = 63, hop = 16, pad = 31, nb = 32, nfr = 1 + (T + 2 * pad - n) / hop;
-    float *specq = specp + nb * nfr;
+    const int fb = BIG ? LOSS_MEL_FB : nfr;       // frames per block (!BIG: one block holds them all)
+    float *specq = specp + nb * fb;
     __syncthreads();
     if (tid < n) {
         float s, c;
@@ -136,33 +143,37 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(const float *__restric
         ts[tid] = -s;
     }
     __syncthreads();
-    for (int it = tid; it < nb * nfr; it += 256) {
-        const int k = it / nfr, fr = it - k * nfr;
-        float pr = 0.f, pi = 0.f, qr = 0.f, qi = 0.f;
-        int idx = 0;
-        for (int i = 0; i < n; ++i) {
-            int s = fr * hop - pad + i;
-            s = s < 0 ? -s : (s >= T ? 2 * (T - 1) - s : s);          // reflect (no edge repeat)
-            const float w = 0.5f - 0.5f * tc[i];                     // periodic Hann: 0.5 - 0.5 cos(2 pi i / n)
-            const float c = tc[idx], sn = ts[idx], a = w * sp[s], b = w * sq[s];
-            pr += a * c; pi += a * sn; qr += b * c; qi += b * sn;
-            idx += k;
-            if (idx >= n) idx -= n;
-        }
-        specp[k * nfr + fr] = pr * pr + pi * pi;
-        specq[k * nfr + fr] = qr * qr + qi * qi;
-    }
-    __syncthreads();
     float macc = 0.f;
-    for (int it = tid; it < 64 * nfr; it += 256) {
-        const int m = it / nfr, fr = it - m * nfr;
-        float a = 0.f, b = 0.f;
-        for (int f = 0; f < nb; ++f) {
-            const float w = melfb[f * 64 + m];
-            a += w * specp[f * nfr + fr];
-            b += w * specq[f * nfr + fr];
+    for (int f0 = 0; f0 < nfr; f0 += fb) {
+        const int nf = min(fb, nfr - f0);             // frames of this block
+        for (int it = tid; it < nb * nf; it += 256) {
+            const int k = it / nf, fr = it - k * nf;
+            float pr = 0.f, pi = 0.f, qr = 0.f, qi = 0.f;
+            int idx = 0;
+            for (int i = 0; i < n; ++i) {
+                int s = (f0 + fr) * hop - pad + i;
+                s = s < 0 ? -s : (s >= T ? 2 * (T - 1) - s : s);          // reflect (no edge repeat)
+                const float w = 0.5f - 0.5f * tc[i];                     // periodic Hann: 0.5 - 0.5 cos(2 pi i / n)
+                const float c = tc[idx], sn = ts[idx], a = w * sp[s], b = w * sq[s];
+                pr += a * c; pi += a * sn; qr += b * c; qi += b * sn;
+                idx += k;
+                if (idx >= n) idx -= n;
+            }
+            specp[k * nf + fr] = pr * pr + pi * pi;
+            specq[k * nf + fr] = qr * qr + qi * qi;
         }
-        macc += fabsf(a - b);
+        __syncthreads();
+        for (int it = tid; it < 64 * nf; it += 256) {
+            const int m = it / nf, fr = it - m * nf;
+            float a = 0.f, b = 0.f;
+            for (int f = 0; f < nb; ++f) {
+                const float w = melfb[f * 64 + m];
+                a += w * specp[f * nf + fr];
+                b += w * specq[f * nf + fr];
+            }
+            macc += fabsf(a - b);
+        }
+        if (BIG) __syncthreads();                     // the tables are refilled by the next block
     }
     const float mel_mean = block_sum(macc, red) / (float)(64 * nfr);
     if (tid == 0) {
@@ -223,13 +234,19 @@ hipError_t loss_tables(hipStream_t st)
     return get_melfb(&fb, st);
 }
 
-// dynamic LDS of loss_finish_kernel: two T-long series, two 64-entry trig tables, 2 x 32 bins x (1 + T/16) mel frames
-size_t perceptual_loss_lds_bytes(int T) { return (size_t)(2 * T + 128 + 2 * 32 * (1 + T / 16)) * sizeof(float); }
+// dynamic LDS of loss_finish_kernel<false>: two T-long series, two 64-entry trig tables, 2 x 32 bins x (1 + T/16) mel frames; it
+// fits the CU's 160 KiB up to T = ADN_LOSS_LDS_T.  <true>: trig tables + one block of mel frames.
+size_t perceptual_loss_lds_bytes(int T)
+{
+    if (T > ADN_LOSS_LDS_T) return (size_t)(128 + 2 * 32 * LOSS_MEL_FB) * sizeof(float);
+    return (size_t)(2 * T + 128 + 2 * 32 * (1 + T / 16)) * sizeof(float);
+}
 
 size_t perceptual_loss_workspace_floats(int n_clips, int F, int T)
 {
     const int nslab = (F + LOSS_ROWS - 1) / LOSS_ROWS;
-    return (size_t)n_clips * nslab * (2 * (size_t)T + 1);
+    // partial column sums of the row slabs (+ beyond ADN_LOSS_LDS_T frames: the two series of every clip)
+    return (size_t)n_clips * nslab * (2 * (size_t)T + 1) + (T > ADN_LOSS_LDS_T ? (size_t)n_clips * 2 * T : 0);
 }
 
 hipError_t launch_perceptual_loss(const float *pred, const float *tgt, int n_clips, int F, int T, float *workspace,
@@ -241,9 +258,10 @@ hipError_t launch_perceptual_loss(const float *pred, const float *tgt, int n_cli
     const int nslab = (F + LOSS_ROWS - 1) / LOSS_ROWS;
     // everything that can fail is checked BEFORE the first launch (nothing is enqueued on an error)
     const size_t lds = perceptual_loss_lds_bytes(T);
-    if (lds > ADN_LOSS_MAX_LDS) return hipErrorInvalidValue;
+    const bool big = T > ADN_LOSS_LDS_T;
+    if (lds > ADN_LOSS_MAX_LDS || (long)n_clips * nslab > 0x7fffffffL) return hipErrorInvalidValue;
     if (lds > 64 * 1024) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(loss_finish_kernel),
+        e = hipFuncSetAttribute(big ? reinterpret_cast<const void *>(loss_finish_kernel<true>) : reinterpret_cast<const void *>(loss_finish_kernel<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
@@ -251,7 +269,9 @@ hipError_t launch_perceptual_loss(const float *pred, const float *tgt, int n_cli
                        workspace);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(loss_finish_kernel, dim3((unsigned)n_clips), dim3(256), lds, st, workspace, F, T, nslab, fb, out);
+    float *series = workspace + (size_t)n_clips * nslab * (2 * (size_t)T + 1);
+    if (big) hipLaunchKernelGGL(loss_finish_kernel<true>, dim3((unsigned)n_clips), dim3(256), lds, st, workspace, F, T, nslab, fb, series, out);
+    else hipLaunchKernelGGL(loss_finish_kernel<false>, dim3((unsigned)n_clips), dim3(256), lds, st, workspace, F, T, nslab, fb, series, out);
     return hipGetLastError();
 }
 

@@ -241,36 +241,39 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             c -= second * (HPX / 2);
             const bool data = row < HP && j < RSL && c < (pair ? HPX / 2 : HP) && n + second < p.N;
             const int y = gy0 + row - s.offY, x = gx0 + c - s.offX;
+            // byte offset inside ONE 8-channel block of the source image (C8 layout); pair mode: the same block of clip n + 1 lies
+            // one image further (the launcher grants pair mode only where that stays inside a descriptor's 4 GB)
             hcur[r] = (data && y >= 0 && y < s.H && x >= 0 && x < s.W)
-                          ? (unsigned)((y * s.W + x) * 8 + half * 4 + second * s.C * s.H * s.W) * 4u : OOB;   // C8 layout
+                          ? ((unsigned)(y * s.W + x) * 8u + (unsigned)(half * 4)) * 4u + (unsigned)second * ((unsigned)(s.C * s.H * s.W) * 4u) : OOB;
         }
     };
-    // descriptor of the current source: the image of clip n (pair mode: clips n, n + 1); soff walks its 8-channel blocks
-    auto src_rsrc = [&](const auto &s) {
-        const unsigned img = (unsigned)(s.C * s.H * s.W) * 4u;
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(static_cast<const float *>(s.ptr)) + (size_t)n * s.H * s.W * s.C, 0,
-                                                 img << pair, 0x00020000);
+    // descriptor of the current source: ONE 8-channel block (H * W * 32 bytes: < 4 GB for every F * T < 2^27) of the image of
+    // clip n (pair mode: reaching into the same block of clip n + 1); its 64-bit base walks the image's blocks chunk by chunk, so
+    // an image may be larger than the 4 GB one descriptor spans
+    const char *hptr;                                   // the next chunk's channel block
+    unsigned cstr, hrange;                              // bytes between consecutive channel blocks of the current source / descriptor range
+    auto src_begin = [&](const auto &s) {
+        const size_t img = (size_t)s.C * s.H * s.W * 4;
+        hptr = static_cast<const char *>(s.ptr) + (size_t)n * img;
+        cstr = (unsigned)(s.H * s.W) * 32u;
+        hrange = cstr + (pair ? (unsigned)img : 0u);
     };
-    __amdgpu_buffer_rsrc_t hrs = src_rsrc(p.s0);
-    unsigned hsoff = 0;                                 // byte offset of the next chunk's channel block
-    unsigned cstr = (unsigned)(p.s0.H * p.s0.W) * 32u;  // bytes between consecutive channel blocks of the current source
+    src_begin(p.s0);
 
     // halo of chunk ch (absolute index): switch of the source at the virtual concat, HR wave-instructions, advance
 #define W4_HALO_BEGIN(ch)                                                                      \
     do {                                                                                       \
         if ((ch) == p.nchunk0) {                      /* wave-uniform: switch to the second source (virtual concat) */ \
-            hrs = src_rsrc(p.s1);                                                              \
-            hsoff = 0;                                                                         \
-            cstr = (unsigned)(p.s1.H * p.s1.W) * 32u;                                          \
+            src_begin(p.s1);                                                                   \
             plan(p.s1);                                                                        \
         }                                                                                      \
     } while (0)
 #define W4_HALO_PIECE(k, buf)                                                                  \
     do {                                                                                       \
         float *dst_ = smem + (buf) * IMG + ((k) * NT + wave * 64) * 4;                         \
-        dma16(hrs, hcur[(k) < HR ? (k) : 0], hsoff, dst_);                                     \
+        dma16(dma_rsrc(hptr, hrange), hcur[(k) < HR ? (k) : 0], 0u, dst_);                     \
     } while (0)
-#define W4_HALO_END() hsoff += cstr
+#define W4_HALO_END() hptr += cstr
     // U slab of the next chunk: UR wave-instructions (the last round exists in waves 0-3 only)
 #define W4_U_PIECE(k, buf)                                                                     \
     do {                                                                                       \
@@ -843,7 +846,7 @@ bool wino4_applicable(ConvKind kind, const ConvArgs &a, bool force)
     if (a.firstw || a.ksplit > 1 || (a.Cout & 31) || a.nchunk < 1) return false;
     // images at most 16 pixels wide run in pair mode: a tile covers 32 rows x 16 columns of each of two clips
     const long th = (a.H + REG - 1) / REG, tw = (a.W + REG - 1) / REG;
-    const long tiled = a.W <= 16 ? th * REG * 16 : th * tw * REG * REG;
+    const long tiled = wino4_pair_mode(a) ? th * REG * 16 : th * tw * REG * REG;
     return force || tiled * 3 <= (long)a.H * a.W * 4;
 }
 
@@ -853,7 +856,7 @@ hipError_t launch_wino4_conv(ConvKind kind, const ConvArgs &a, hipStream_t st)
     ConvArgs a2 = a;
     a2.tilesY = (a.H + REG - 1) / REG;
     a2.tilesX = (a.W + REG - 1) / REG;
-    a2.pair = a.W <= 16 ? 1 : 0;
+    a2.pair = wino4_pair_mode(a) ? 1 : 0;
     a2.nct = a.Cout / 32;
     const long gc = a2.nct < SUP ? a2.nct : SUP, gp = SUP / gc;
     const long ptiles = (long)((a2.N + a2.pair) >> a2.pair) * a2.tilesY * a2.tilesX;

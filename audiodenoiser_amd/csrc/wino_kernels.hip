@@ -153,10 +153,11 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
         const bool data = s < G::HUSED && !(NW == 4 && k == 16) && pix < G::HW;
         const int gy = gy0 + row, gx = gx0 + pix;
         const int y0 = gy - p.s0.offY, x0 = gx - p.s0.offX;
-        // byte offsets inside the source image (C8 layout), ADN_DMA_OOB = padding (the copy writes zeros)
-        hcur[r] = (data && y0 >= 0 && y0 < p.s0.H && x0 >= 0 && x0 < p.s0.W) ? ((y0 * p.s0.W + x0) * 8 + part * 4) * 4 : (int)ADN_DMA_OOB;
+        // byte offsets inside ONE 8-channel block of the source image (C8 layout; unsigned: H * W * 32 bytes may pass 2^31),
+        // ADN_DMA_OOB = padding (the copy writes zeros)
+        hcur[r] = (data && y0 >= 0 && y0 < p.s0.H && x0 >= 0 && x0 < p.s0.W) ? (int)(((unsigned)(y0 * p.s0.W + x0) * 8u + (unsigned)(part * 4)) * 4u) : (int)ADN_DMA_OOB;
         const int y1 = gy - p.s1.offY, x1 = gx - p.s1.offX;
-        hsec[r] = (data && y1 >= 0 && y1 < p.s1.H && x1 >= 0 && x1 < p.s1.W) ? ((y1 * p.s1.W + x1) * 8 + part * 4) * 4 : (int)ADN_DMA_OOB;
+        hsec[r] = (data && y1 >= 0 && y1 < p.s1.H && x1 >= 0 && x1 < p.s1.W) ? (int)(((unsigned)(y1 * p.s1.W + x1) * 8u + (unsigned)(part * 4)) * 4u) : (int)ADN_DMA_OOB;
     }
     if constexpr (SRC == 1) {
         // plan of the fused first layer: hcur = index of the slot's 3x3 input window in the LDS copy (-1: the halo pixel
@@ -175,23 +176,20 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
     }
     float *const sX = smem + 2 * DBUF;                 // SRC == 1: input window [20][20], then weights [9][64] + bias [64]
     float *const sW = sX + XWIN;
-    // descriptor of the current source (the image of clip n) and the byte offset of the next chunk's 8-channel block in it
-    auto src_rsrc = [&](const ConvSrc &s) {
-        return dma_rsrc(static_cast<const float *>(s.ptr) + (size_t)n * s.H * s.W * s.C, (unsigned)(s.C * s.H * s.W) * 4u);
-    };
-    __amdgpu_buffer_rsrc_t hrs = src_rsrc(p.s0);
-    unsigned cstr = (unsigned)(p.s0.H * p.s0.W) * 32u;
+    // descriptor of the current source: ONE 8-channel block (H * W * 32 bytes: < 4 GB for every F * T < 2^27) of the image of clip
+    // n; its 64-bit base walks the image's blocks chunk by chunk (an image may be larger than the 4 GB one descriptor spans)
+    auto src_base = [&](const ConvSrc &s) { return static_cast<const char *>(s.ptr) + (size_t)n * s.H * s.W * s.C * 4; };
+    const char *hptr = src_base(p.s0);                  // the next chunk's channel block
+    unsigned cstr = (unsigned)(p.s0.H * p.s0.W) * 32u;  // bytes between consecutive channel blocks = descriptor range
     const unsigned cstr1 = (unsigned)(p.s1.H * p.s1.W) * 32u;
-    unsigned hsoff = 0;
     if (SPLIT) {
         if (c0 >= p.nchunk0) {                            // the slice starts inside the second source (virtual concat)
-            hrs = src_rsrc(p.s1);
-            hsoff = (unsigned)(c0 - p.nchunk0) * cstr1;
+            hptr = src_base(p.s1) + (size_t)(c0 - p.nchunk0) * cstr1;
             cstr = cstr1;
 #pragma unroll
             for (int r = 0; r < HR; ++r) hcur[r] = hsec[r];
         } else {
-            hsoff = (unsigned)c0 * cstr;
+            hptr += (size_t)c0 * cstr;
         }
     }
 
@@ -219,8 +217,7 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
     do {                                                                                       \
         if constexpr (SRC == 0) {                                                              \
         if ((c) == p.nchunk0) {                       /* wave-uniform: switch to the second source */ \
-            hrs = src_rsrc(p.s1);                                                              \
-            hsoff = 0;                                                                         \
+            hptr = src_base(p.s1);                                                             \
             cstr = cstr1;                                                                      \
             _Pragma("unroll") for (int r = 0; r < HR; ++r) hcur[r] = hsec[r];                  \
         }                                                                                      \
@@ -232,12 +229,12 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
         float *dst_ = smem + (buf) * DBUF + wave * 256 + (k) * NT * 4;                         \
         if ((k) < HR) {                                                                        \
             if constexpr (SRC == 1) first_piece((k) < HR ? (k) : 0, (buf));                    \
-            else dma16_buf(hrs, (unsigned)hcur[(k) < HR ? (k) : 0], hsoff, dst_);              \
+            else dma16_buf(dma_rsrc(hptr, cstr), (unsigned)hcur[(k) < HR ? (k) : 0], 0u, dst_); \
         } else dma16_buf(urs, uoff, usoff + ((k) - HR) * NT * 16, dst_);                       \
     } while (0)
 #define ADN_DMA_END()                                                                          \
     do {                                                                                       \
-        hsoff += cstr;                                                                         \
+        hptr += cstr;                                                                          \
         usoff += 16384;                                                                        \
         ++fchunk;                                                                              \
     } while (0)

@@ -86,8 +86,8 @@ ADN_API int adn_unet_create(adn_unet **handle, int device, const float *const *h
 ADN_API int adn_unet_create_ex(adn_unet **handle, int device, const float *const *host_tensors, int n_tensors, int dtype);
 /* UNet(in_channels, num_classes) as the reference declares it (code/model.py:54,56,68; its own callers use (1, 1), test.py:63):
  * the same 118 tensors with downconv1.conv.double_conv.0.weight (64, in_channels, 3, 3), out.weight (num_classes, 64, 1, 1) and
- * out.bias (num_classes).  x is then (N, in_channels, F, T) and y (N, num_classes, F, T), both NCHW fp32.  1 <= in_channels <= 15
- * (and in_channels * (T + 2) <= 4096), 1 <= num_classes <= 64.  With more than one input plane / class the first / last
+ * out.bias (num_classes).  x is then (N, in_channels, F, T) and y (N, num_classes, F, T), both NCHW fp32.  1 <= in_channels <= 15,
+ * 1 <= num_classes <= 64.  With more than one input plane / class the first / last
  * convolution run as their own launches (the fused forms are for one plane / one class). */
 ADN_API int adn_unet_create_general(adn_unet **handle, int device, const float *const *host_tensors, int n_tensors, int dtype,
                             int in_channels, int num_classes);
@@ -108,7 +108,8 @@ ADN_API int adn_unet_workspace_bytes(const adn_unet *handle, int N, int F, int T
 /* y(N,K,F,T) = UNet(x(N,C,F,T)) (C = K = 1 unless the handle came from adn_unet_create_general), eval-mode semantics
  * (BatchNorm uses running statistics), fp32.
  * x, y, workspace: device memory on the handle's device.  F,T >= 16 (four 2x poolings). */
-/* Shape limits: N >= 1, F >= 16, 16 <= T <= 4094, F*T < 2^24 (ADN_ERR_INVALID otherwise). */
+/* Shape limits: N >= 1, F >= 16, T >= 16, F*T < 2^27 (ADN_ERR_INVALID otherwise) -- e.g. 513 bins x 261 000 frames; the workspace
+ * (adn_unet_workspace_bytes: ~1.1 KB per pixel in fp32, half in fp16) is the practical bound. */
 ADN_API int adn_unet_forward(adn_unet *handle, const float *x, float *y, int N, int F, int T,
                      void *workspace, size_t workspace_bytes, void *stream);
 
@@ -157,10 +158,9 @@ ADN_API int adn_per_clip_l1(const float *a, const float *b, int n_clips, long el
  * calls (code/loss.py:6-95; caller code/test.py:118-122).  pred, target: (n_clips,1,F,T) fp32 device tensors;
  * out: (n_clips,4) = {total, stft, mel, l1}.  The reference's batch values are the means over clips (equal clip
  * sizes).  Constants are the reference's: scales (63,16),(32,8),(16,4); mel: sr 8000, n_fft 63, hop 16, 64 mels;
- * weights 0.4/0.4/0.2.  Needs 32 <= T <= ADN_LOSS_MAX_FRAMES (one clip's frequency-mean series, trig tables and mel
- * frames are held in the 160 KiB LDS of one CU; ADN_ERR_INVALID outside, before anything is enqueued) and
- * adn_perceptual_loss_workspace_bytes of device scratch. */
-#define ADN_LOSS_MAX_FRAMES 6784
+ * weights 0.4/0.4/0.2.  Needs T >= 32 (the mel term's reflect padding; the reference raises below that too) and
+ * adn_perceptual_loss_workspace_bytes of device scratch.  Up to 6784 frames a clip's frequency-mean series and mel spectra are held
+ * in the LDS of one CU; longer clips (no limit in the reference) keep the series in the workspace and walk the mel frames in blocks. */
 ADN_API int adn_perceptual_loss_workspace_bytes(int n_clips, int F, int T, size_t *bytes);
 ADN_API int adn_perceptual_loss(const float *pred, const float *target, int n_clips, int F, int T, void *workspace,
                         size_t workspace_bytes, float *out, void *stream);

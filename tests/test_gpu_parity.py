@@ -610,9 +610,10 @@ def test_perceptual_loss_per_clip(dev, b, f, t):
     assert abs(float(total) - float(ref[:, 0].mean())) < 1e-4 * float(ref[:, 0].mean())
 
 
-@pytest.mark.parametrize("t", [2688, 2704, 4094, 6784])
+@pytest.mark.parametrize("t", [2688, 2704, 4094, 6784, 6785, 8192, 20001, 65535])
 def test_perceptual_loss_long_clips(dev, t):
-    """Frame counts beyond 64 KiB of LDS per clip (T >= 2689) up to the documented limit ADN_LOSS_MAX_FRAMES."""
+    """Frame counts beyond 64 KiB of LDS per clip (T >= 2689), up to what one CU's LDS holds (6784), and beyond it (the series
+    then live in the workspace and the mel frames are walked in blocks): the reference's loss has no length limit."""
     from oracle import loss_torch
     from audiodenoiser_amd.loss import perceptual_loss_per_clip
     g = torch.Generator().manual_seed(t)
@@ -621,10 +622,6 @@ def test_perceptual_loss_long_clips(dev, t):
     ref = loss_torch.per_clip(pred, tgt).numpy()
     got = perceptual_loss_per_clip(pred.to(dev), tgt.to(dev)).cpu().numpy()
     assert np.allclose(got, ref, rtol=2e-4, atol=1e-6)
-    from audiodenoiser_amd._lib import AdnError
-    if t == 6784:
-        with pytest.raises(AdnError, match="6784"):
-            perceptual_loss_per_clip(torch.zeros((1, 1, 8, t + 1), device=dev), torch.zeros((1, 1, 8, t + 1), device=dev))
 
 
 def test_perceptual_loss_zero_and_errors(dev):

@@ -403,16 +403,18 @@ def test_cpu_tensors_without_a_device_raise_instead_of_computing(weights_np):
 def test_perceptual_loss_frame_limit_is_reported_before_any_launch():
     from audiodenoiser_amd import _lib
     L = _lib.load()
-    header = open(os.path.join(ROOT, "include", "adn.h")).read()
-    tmax = int(re.search(r"#define ADN_LOSS_MAX_FRAMES (\d+)", header).group(1))
+    tlds = 6784                                   # up to here a clip's series and mel frames live in one CU's LDS (adn.h)
     need = ctypes.c_size_t()
-    assert L.adn_perceptual_loss_workspace_bytes(2, 513, tmax, ctypes.byref(need)) == 0
-    assert need.value == 2 * 17 * (2 * tmax + 1) * 4
-    assert L.adn_perceptual_loss_workspace_bytes(2, 513, tmax + 1, ctypes.byref(need)) == 1
+    assert L.adn_perceptual_loss_workspace_bytes(2, 513, tlds, ctypes.byref(need)) == 0
+    assert need.value == 2 * 17 * (2 * tlds + 1) * 4
+    # longer clips (round 5: no limit, as in the reference): the two series of every clip join the workspace
+    assert L.adn_perceptual_loss_workspace_bytes(2, 513, tlds + 1, ctypes.byref(need)) == 0
+    assert need.value == (2 * 17 * (2 * (tlds + 1) + 1) + 2 * 2 * (tlds + 1)) * 4
+    assert L.adn_perceptual_loss_workspace_bytes(1, 513, 1 << 25, ctypes.byref(need)) == 1
     buf = (ctypes.c_float * 16)()
     p = ctypes.cast(buf, ctypes.c_void_p)
-    assert L.adn_perceptual_loss(p, p, 1, 64, tmax + 1, p, 1 << 40, p, None) == 1     # rejected on the host
-    assert b"6784" in L.adn_last_error()
+    assert L.adn_perceptual_loss(p, p, 1, 64, 1 << 25, p, 1 << 40, p, None) == 1     # rejected on the host
+    assert b"2^24" in L.adn_last_error()
     assert L.adn_perceptual_loss(p, p, 1, 64, 31, p, 1 << 40, p, None) == 1           # reflect pad of 31 needs T >= 32 (loss.py:39-41)
     assert b"32 <= T" in L.adn_last_error()
     assert L.adn_perceptual_loss_workspace_bytes(1, 64, 31, ctypes.byref(need)) == 1
@@ -463,9 +465,11 @@ def test_forward_shape_limits_are_reported():
     L = _lib.load()
     need = ctypes.c_size_t()
     assert L.adn_unet_workspace_bytes(None, 1, 64, 4094, ctypes.byref(need)) == 0
-    assert L.adn_unet_workspace_bytes(None, 1, 64, 4096, ctypes.byref(need)) == 1
-    assert b"T<=4094" in L.adn_last_error()
-    assert L.adn_unet_workspace_bytes(None, 1, 8192, 4000, ctypes.byref(need)) == 1
+    assert L.adn_unet_workspace_bytes(None, 1, 64, 65536, ctypes.byref(need)) == 0           # no limit on T by itself (round 5)
+    assert L.adn_unet_workspace_bytes(None, 1, 8192, 4000, ctypes.byref(need)) == 0 and need.value > 8192 * 4000 * 64 * 4 * 2
+    assert L.adn_unet_workspace_bytes(None, 1, 513, 261000, ctypes.byref(need)) == 0         # F*T just below 2^27
+    assert L.adn_unet_workspace_bytes(None, 1, 8192, 16384, ctypes.byref(need)) == 1         # F*T = 2^27
+    assert b"F*T<2^27" in L.adn_last_error()
 
 
 def test_bf16_three_term_split_is_fp32_accurate():
