@@ -23,7 +23,8 @@ __host__ __device__ __forceinline__ long act_off(int C, long HW, long pix, int c
 }
 
 // LDS-DMA through a buffer descriptor (buffer_load_dwordx4 ... offen lds): lane l of the wave copies the 16 bytes at
-// descriptor base + voff + soff to lds_wave_base + 16 l.  The range check compares voff with the descriptor's size, and a
+// descriptor base + voff + soff to lds_wave_base + 16 l.  The range check compares voff with the descriptor's size MINUS soff
+// (measured in round 5: a scalar offset that leaves the range drops the access although voff alone is inside), and a
 // lane that fails it writes ZEROS into its LDS slot (tools/ubench/buffer_lds_oob.hip): the convolutions' zero padding and the
 // pad slots of the LDS layouts cost no select against a zero block and no 64-bit address arithmetic -- a copy piece is one
 // scalar add and the instruction.  ADN_DMA_OOB: voff of a padding lane (every image is smaller than that: F*T < 2^24).

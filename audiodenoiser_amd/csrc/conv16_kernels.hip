@@ -139,8 +139,8 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
         ppx[k] = (q >> 1) | ((q & 1) << 16);        // pixel, half in bit 16
     }
     // descriptors are rebuilt from scalars at every use (two SALU operations) instead of being carried through the loop; a halo
-    // descriptor spans ONE channel block (H * W * 32 bytes: < 4 GB for every F * T < 2^27) -- its 64-bit base moves with the chunk,
-    // so an image may exceed the 4 GB one descriptor spans
+    // descriptor spans the TWO channel blocks of a chunk (H * W * 64 bytes: conv16_applicable admits only images for which that
+    // stays below 4 GB) -- its 64-bit base moves with the chunk, so an image may exceed the 4 GB one descriptor spans
     const char *hbase = nullptr;                    // image of clip n in the current source
     unsigned hblk_bytes = 0;                        // bytes of one of its channel blocks (H * W * 32)
     auto plan = [&](const ConvSrc &s, const C16Item &it) {
@@ -268,9 +268,10 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
         hb_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(hb >> 32));
         wsoff = (unsigned)__builtin_amdgcn_readfirstlane((fi.ct * nchunk + f_chunk) * (C16_W_SLOTS * 16));
     };
-    // descriptor of the chunk's FIRST block; its second block is reached through the scalar offset (which the range check ignores)
+    // descriptor of the chunk's two blocks; the second one is reached through the scalar offset, which the hardware's range
+    // check counts (out of range: vector offset >= num_records - scalar offset), so the range covers both blocks
     auto halo_rsrc = [&]() {
-        return dma_rsrc(reinterpret_cast<const void *>(((unsigned long long)hb_hi << 32) | hb_lo), (unsigned)__builtin_amdgcn_readfirstlane((int)hblk_bytes));
+        return dma_rsrc(reinterpret_cast<const void *>(((unsigned long long)hb_hi << 32) | hb_lo), 2u * (unsigned)__builtin_amdgcn_readfirstlane((int)hblk_bytes));
     };
     auto halo_soff = [&](int q) {                   // pieces 0, 1: block 0; 3, 4: block 1; piece 2: waves 0-3 block 0, 4-7 block 1
         const unsigned h1 = (unsigned)__builtin_amdgcn_readfirstlane((int)hblk_bytes);
@@ -466,15 +467,15 @@ __global__ __launch_bounds__(C16_NT, 2) void conv16_f16(const ConvArgs p)
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v + p.dot_bias), yrs, off, 0, 0);
                 }
             } else {
-                // output descriptors span ONE channel block (H * W * 32 bytes), based at this item's first block; the four blocks of
-                // the cout tile follow at scalar offsets of one block each (block 3 at 3 * HWb: conv16_applicable admits a layer
-                // only where that stays below 2^32 -- images of up to 44 million pixels; larger ones run on conv_dma<_Float16>)
+                // output descriptors span the FOUR channel blocks of the item's cout tile (H * W * 128 bytes, based at its first
+                // block; blocks 1-3 at scalar offsets of one block each): conv16_applicable admits a layer only where that stays
+                // below 4 GB -- images of up to 33 million pixels; larger ones run on conv_dma<_Float16>
                 const unsigned HWb = (unsigned)(p.H * p.W) * 32u;          // bytes of one channel block of the output
-                const __amdgpu_buffer_rsrc_t ors = dma_rsrc(static_cast<const char *>(p.out) + ((size_t)ci.n * p.Cout * p.H * p.W + (size_t)ci.ct * 64 * p.H * p.W) * 2, HWb);
+                const __amdgpu_buffer_rsrc_t ors = dma_rsrc(static_cast<const char *>(p.out) + ((size_t)ci.n * p.Cout * p.H * p.W + (size_t)ci.ct * 64 * p.H * p.W) * 2, 4u * HWb);
                 const int Hp = p.H >> 1, Wp = p.W >> 1;
                 const unsigned HWpb = (unsigned)(Hp * Wp) * 32u;
                 const __amdgpu_buffer_rsrc_t prs = dma_rsrc(EPI == CONV3X3_RELU_POOL ? static_cast<const char *>(p.pool) + ((size_t)ci.n * p.Cout * Hp * Wp + (size_t)ci.ct * 64 * Hp * Wp) * 2 : nullptr,
-                                                            EPI == CONV3X3_RELU_POOL ? HWpb : 0u);
+                                                            EPI == CONV3X3_RELU_POOL ? 4u * HWpb : 0u);
                 unsigned ooff[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -608,8 +609,11 @@ hipError_t launch_c16(const ConvArgs &a, hipStream_t st)
 bool conv16_applicable(ConvKind kind, const ConvArgs &a)
 {
     if (kind != CONV3X3_RELU && kind != CONV3X3_RELU_POOL && kind != CONV3X3_RELU_DOT) return false;
-    // output blocks are addressed by 32-bit scalar offsets of up to three channel blocks (H * W * 32 bytes each)
-    if ((size_t)a.H * a.W * 96 >= (size_t)0xfffffff0u) return false;
+    // the four output blocks of an item (H * W * 32 bytes each) and the two input blocks of a chunk are addressed through one
+    // buffer descriptor each (vector + scalar offset below its 32-bit range)
+    if ((size_t)a.H * a.W * 128 >= (size_t)0xfffffff0u || (size_t)a.s0.H * a.s0.W * 64 >= (size_t)0xfffffff0u ||
+        (size_t)a.s1.H * a.s1.W * 64 >= (size_t)0xfffffff0u)
+        return false;
     {   // the item decode divides by multiply-high with launch constants: exact while item count x divisor < 2^32 (c16_decode)
         const long ty = (a.H + C16_TH - 1) / C16_TH, tx = (a.W + C16_TW - 1) / C16_TW, nct = a.Cout / 64;
         const long nitems = (long)a.N * ty * tx * nct, maxd = std::max(nct, std::max(tx, ty));
