@@ -80,6 +80,7 @@ struct Conv3x3Layer {
 struct ConvTLayer {
     int Cin, Cout;
     size_t w_off, b_off;
+    size_t w16_off, braw_off;   // fp16 path: pack_convt16 form of the weights (convt16_f16), 0 = none; the Cout biases as they are
 };
 
 }  // namespace
@@ -120,6 +121,8 @@ struct adn_unet {
     // fp16 path, 3x3 layers: 0 = conv_dma<_Float16> (32x32x16 MFMA, rounds 1-3) everywhere, 1 = conv16_f16 (16x16x32 MFMA,
     // persistent, LDS-resident weights for the 64 -> 64 layers) wherever it applies = the default (ADN_F16_CONV=32 / 16)
     int f16_conv = 1;
+    int f16_convt = 1;             // fp16 transposed convolutions: 1 = convt16_f16 (16x16x32 MFMA, persistent; default), 0 = conv_dma<_Float16>
+                                   // (ADN_F16_CONVT=dma when the handle is created)
     bool f16_fuse_first = true;    // ADN_F16_FIRST=0: Conv2d(1 -> 64) as its own launch (conv_first_kernel) on the fp16 path (A/B runs)
     bool batch_invariant = false;
     // thresholds of the rule, in F(4x4,3x3) workgroups of the launch, calibrated on per-launch timings at batch 1-16
@@ -273,6 +276,27 @@ void pack_convt(const float *w /*(Cin,Cout,2,2)*/, int Cin, int Cout, T *dst)
                             dst[o++] = (T)w[((size_t)ci * Cout + co) * 4 + ij];
                         }
                     }
+}
+
+// fp16 weights for convt16_f16 (convt16_kernels.hip): GEMM columns come in PAIRS of 16-column blocks -- the same 16 output channels
+// at dj = 0 and dj = 1 --, pair P = di * (Cout / 16) + (16-channel group), eight pairs (256 columns) per column tile:
+// [column tile][chunk of 32 channels][column block cb = 2 * (pair % 8) + dj][k group g][column % 16][8 halfs], input channel =
+// chunk*32 + 8g + e: the W fragment of a column block is 64 lanes x 16 bytes = 1 KB contiguous, lane = 16 g + column % 16.
+void pack_convt16(const float *w /*(Cin,Cout,2,2)*/, int Cin, int Cout, _Float16 *dst)
+{
+    const int nchunk = Cin / 32, npair = Cout / 16, nct = Cout / 64;
+    for (int ct = 0; ct < nct; ++ct)
+        for (int ch = 0; ch < nchunk; ++ch)
+            for (int cb = 0; cb < 16; ++cb) {
+                const int P = ct * 8 + (cb >> 1), dj = cb & 1, di = P / npair, cg = P % npair;
+                for (int g = 0; g < 4; ++g)
+                    for (int c16 = 0; c16 < 16; ++c16)
+                        for (int e = 0; e < 8; ++e) {
+                            const int ci = ch * 32 + 8 * g + e, co = cg * 16 + c16;
+                            dst[(((((size_t)ct * nchunk + ch) * 16 + cb) * 4 + g) * 16 + c16) * 8 + e] =
+                                (_Float16)w[(((size_t)ci * Cout + co) * 2 + di) * 2 + dj];
+                        }
+            }
 }
 
 // The same GEMM for the split-bf16 form of conv_dma (fp32 path; conv_kernels.hip, SPLIT): every weight is written as three bf16
@@ -613,7 +637,17 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
         t.split = h->convt_split ? 1 : 0;
         t.nwg_total = 0;
         ADN_MARK();
-        ADN_HIP(adn::launch_conv_mfma(adn::CONVT2X2, t, f16, st));
+        bool t16 = false;
+        if (f16 && TL.w16_off) {                         // fp16: convt16_f16 wherever it applies (convt16_kernels.hip)
+            adn::ConvArgs t2 = t;
+            t2.wpk = h->dev + TL.w16_off;
+            t2.bias = h->dev + TL.braw_off;
+            if (adn::convt16_applicable(t2)) {
+                ADN_HIP(adn::launch_convt16(t2, st));
+                t16 = true;
+            }
+        }
+        if (!t16) ADN_HIP(adn::launch_conv_mfma(adn::CONVT2X2, t, f16, st));
         // first conv of the DoubleConv reads cat([skip, x1]) virtually
         adn::ConvArgs a = conv_args(h, h->c3[li], adn::CONV3X3_RELU, ws + p.skip[l], co, Y, co, 2 * uh, 2 * uw, X, nullptr,
                                     N, p.H[l], p.W[l]);
@@ -765,6 +799,7 @@ int adn_unet_create_general(adn_unet **handle, int device, const float *const *t
     if (const char *bi = std::getenv("ADN_BATCH_INVARIANT")) h->batch_invariant = std::atoi(bi) != 0;
     if (const char *ff = std::getenv("ADN_F16_FIRST")) h->f16_fuse_first = std::atoi(ff) != 0;
     if (const char *fc = std::getenv("ADN_F16_CONV")) h->f16_conv = std::atoi(fc) == 32 ? 0 : 1;
+    if (const char *ft = std::getenv("ADN_F16_CONVT")) h->f16_convt = std::strcmp(ft, "dma") == 0 ? 0 : 1;
     if (const char *ag = std::getenv("ADN_AUTO_GRID")) h->auto_grid = std::atol(ag);      // tuning knobs of the small-grid rule
     if (const char *ag = std::getenv("ADN_AUTO_GRID64")) h->auto_grid64 = std::atol(ag);
     if (h->f16) h->convt_split = false;
@@ -835,9 +870,16 @@ int adn_unet_create_general(adn_unet **handle, int device, const float *const *t
         ConvTLayer &TL = h->ct[3 - l];
         TL.Cin = cin;
         TL.Cout = co;
+        TL.w16_off = TL.braw_off = 0;
         if (h->f16) {
             TL.w_off = reserve(((size_t)4 * cin * co + 1) / 2);
             pack_convt<_Float16>(t[ti], cin, co, reinterpret_cast<_Float16 *>(host.data() + TL.w_off));
+            if (h->f16_convt != 0 && cin % 128 == 0 && co % 64 == 0) {
+                TL.w16_off = reserve(((size_t)4 * cin * co + 1) / 2);
+                pack_convt16(t[ti], cin, co, reinterpret_cast<_Float16 *>(host.data() + TL.w16_off));
+                TL.braw_off = reserve(co);
+                std::memcpy(host.data() + TL.braw_off, t[ti + 1], sizeof(float) * co);
+            }
         } else if (h->convt_split) {
             TL.w_off = reserve(((size_t)3 * 4 * cin * co + 1) / 2);          // three bf16 planes
             pack_convt_split(t[ti], cin, co, reinterpret_cast<uint16_t *>(host.data() + TL.w_off));

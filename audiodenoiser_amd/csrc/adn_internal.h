@@ -157,6 +157,12 @@ hipError_t launch_wino4_conv(ConvKind kind, const ConvArgs &a, hipStream_t st);
 bool conv16_applicable(ConvKind kind, const ConvArgs &a);
 hipError_t launch_conv16(ConvKind kind, const ConvArgs &a, bool resident, hipStream_t st);
 
+// fp16 transposed convolutions on v_mfma_f32_16x16x32_f16 (convt16_kernels.hip): items of 256 pixels x 256 columns, persistent
+// workgroups, 16-byte stores from the accumulators; weights from ConvArgs::wpk in pack_convt16 layout, ConvArgs::bias = the
+// layer's Cout biases (plain), N / H / W = the INPUT's
+bool convt16_applicable(const ConvArgs &a);
+hipError_t launch_convt16(const ConvArgs &a, hipStream_t st);
+
 // First layer: Conv2d(1 -> 64, 3x3, pad 1) + folded BN + ReLU, fp32 input, blocked-layout output.  w9x64: [tap][cout].
 hipError_t launch_conv_first(const float *x, const float *w9x64, const float *bias, void *out, bool f16,
                              int N, int H, int W, int Cin, hipStream_t st);

@@ -197,6 +197,7 @@ ADN_API int adn_istft(const float *spec, int n_clips, int n_frames, int n_fft, i
  *   ADN_CONVT_SPLIT=0        fp32 transposed convolutions on the exact-fp32 MFMA instead of the three-term bf16 split
  *   ADN_F16_CONV=32          fp16 3x3 layers on conv_dma<_Float16> (32x32x16 MFMA) instead of conv16_f16 (16x16x32)
  *   ADN_F16_FIRST=0          fp16: Conv2d(1 -> 64) as its own launch instead of fused into down1's second convolution
+ *   ADN_F16_CONVT=dma        fp16 transposed convolutions on conv_dma<_Float16> (32x32x16 MFMA, LDS-staged stores) instead of convt16_f16
  *
  * The library reads no other environment variable; its sources contain no timing-experiment code. */
 

@@ -672,28 +672,31 @@ def test_convt_split_bf16_matches_exact_fp32_form(dev, weights_np, golden_dir, m
 
 
 # ---------------------------------------------------------------------------------------------- fp16 path
-@pytest.mark.parametrize("conv", ["default", "first0", "32"])
+@pytest.mark.parametrize("conv", ["default", "first0", "32", "convt_dma"])
 def test_fp16_path_within_1e2_of_fp32_reference(dev, weights_np, golden_dir, conv, monkeypatch):
     """BASELINE configs[4]: fp16 storage + fp16 MFMA (fp32 accumulate); outputs within 1e-2 (relative to max|ref|)
     of the fp32 reference goldens, on every golden shape, and block outputs within 1e-2 of their rms.  Both 3x3 kernel
     families: conv16_f16 (16x16x32 MFMA; the default, with Conv2d(1 -> 64) computed inside down1's second conv, and with
     ADN_F16_FIRST=0 as its own launch: down1's second conv then runs the resident-weight pooling form) and
-    conv_dma<_Float16> (32x32x16, ADN_F16_CONV=32)."""
+    conv_dma<_Float16> (32x32x16, ADN_F16_CONV=32); and both transposed-convolution kernels: convt16_f16 (the default) and
+    conv_dma<_Float16, ..., CONVT2X2> (ADN_F16_CONVT=dma)."""
     from audiodenoiser_amd.model import UNet
     from audiodenoiser_amd.weights import make_input
-    monkeypatch.delenv("ADN_F16_CONV", raising=False)
-    monkeypatch.delenv("ADN_F16_FIRST", raising=False)
+    for k in ("ADN_F16_CONV", "ADN_F16_FIRST", "ADN_F16_CONVT"):
+        monkeypatch.delenv(k, raising=False)
     if conv == "32":
         monkeypatch.setenv("ADN_F16_CONV", conv)
     elif conv == "first0":
         monkeypatch.setenv("ADN_F16_FIRST", "0")
+    elif conv == "convt_dma":
+        monkeypatch.setenv("ADN_F16_CONVT", "dma")
     m = UNet(1, 1)
     m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in weights_np.items()}, strict=True)
     m = m.to(dev).eval().set_compute_dtype("f16")
     with torch.no_grad():
         m(torch.zeros((1, 1, 16, 16), device=dev))               # the handle (and its switches) is created at the first forward
-    monkeypatch.delenv("ADN_F16_CONV", raising=False)
-    monkeypatch.delenv("ADN_F16_FIRST", raising=False)
+    for k in ("ADN_F16_CONV", "ADN_F16_FIRST", "ADN_F16_CONVT"):
+        monkeypatch.delenv(k, raising=False)
     for (n, f, t) in GOLDEN_SHAPES + ((3, 20, 36), (2, 31, 16)):
         if (f, t) not in [(s[1], s[2]) for s in GOLDEN_SHAPES]:
             import oracle
@@ -988,3 +991,36 @@ def test_split_k_small_batch_path(dev, weights_np, golden_dir, monkeypatch):
             s_, sa, sq, cnt = g[f"{name}_stats"]
             assert np.abs(a[g[f"{name}_idx"]] - g[f"{name}_val"]).max() <= 10 * TOL * np.sqrt(sq / cnt), name
             assert abs(np.abs(a).sum() - sa) <= TOL * sa, name
+
+
+def test_fp16_transposed_convolution_kernels_agree(dev, weights_np, monkeypatch):
+    """convt16_f16 (16x16x32 MFMA, 16-byte stores through v_permlane16_swap) against conv_dma<_Float16, ..., CONVT2X2>: the same
+    fp16 products summed in fp32 in a different order -- the four up-path taps and the output agree to fp16 rounding, on shapes
+    with partial tiles (rows / columns beyond the image), several tiles per image and a batch."""
+    from audiodenoiser_amd.model import UNet
+    from audiodenoiser_amd.weights import make_input
+
+    def net(env):
+        for k in ("ADN_F16_CONV", "ADN_F16_FIRST", "ADN_F16_CONVT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m = UNet(1, 1)
+        m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in weights_np.items()}, strict=True)
+        m = m.to(dev).eval().set_compute_dtype("f16")
+        with torch.no_grad():
+            m(torch.zeros((1, 1, 16, 16), device=dev))
+        return m
+    new, old = net({}), net({"ADN_F16_CONVT": "dma"})
+    monkeypatch.delenv("ADN_F16_CONVT", raising=False)
+    for (n, f, t) in ((1, 16, 16), (3, 33, 47), (2, 257, 188), (2, 513, 256), (1, 600, 300), (5, 48, 1040)):
+        x = torch.from_numpy(make_input(5, n, f, t)).to(dev)
+        with torch.no_grad():
+            yn, tn = new(x, return_taps=True)
+            yo, to = old(x, return_taps=True)
+        for name in ("up1", "up2", "up3", "up4"):
+            a, b = tn[name], to[name]
+            assert bool(torch.isfinite(a).all())
+            d = float((a - b).abs().max()) / float(b.abs().max())
+            assert d <= 4e-3, (n, f, t, name, d)                 # (fp16 storage: 1 ulp = 1e-3 relative; later taps compound)
+        assert float((yn - yo).abs().max()) <= 4e-3 * float(yo.abs().max()), (n, f, t)
