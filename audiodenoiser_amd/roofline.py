@@ -9,7 +9,8 @@ from __future__ import annotations
 
 PEAK_MFMA_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: 256 CU x 2.4 GHz x 256 FLOP/clk, v_mfma_f32_32x32x2_f32
 PEAK_MFMA_F16_TFLOPS = 2516.6  # dense fp16 MFMA (16x the fp32 rate), MI355X_MICROARCH.md
-PEAK_HBM_GBS = 8000.0          # HBM3E spec; ~6.3 TB/s achievable
+PEAK_HBM_GBS = 8000.0          # HBM3E spec
+ACHIEVABLE_HBM_GBS = 6300.0    # measured float4 copy rate (MI355X_MICROARCH.md: 6.29 TB/s, 79 % of the spec)
 
 
 def _ceil_to(v: int, m: int) -> int:
@@ -54,15 +55,15 @@ def executed_mfma_flops(launch: dict, algo: str, wino_mode: str = "auto") -> flo
     ``winograd_tile`` says so; wino_conv_dma_f32 =
     F(2x2,3x3), 16 multiply-adds per 2x2 tile = 8 FLOP per padded pixel on 16x16 tiles, elsewhere), "direct"
     (conv_mfma<float>: TH x 16 tiles with TH = 16 for the 64-channel layers and 8 otherwise, 18 FLOP per pixel) or
-    "direct_f16" (conv16_f16 / conv_dma<_Float16>: 32 x 16 tiles for every layer).  Transposed convolutions run
-    conv_dma<T, 8, 128, ...>: K = Cin, 4*Cout GEMM columns, 8 x 16 tiles of input pixels.  The first (Cin = 1) and
-    last (1x1, Cout = 1) layers do not use the matrix cores: 0."""
+    "direct_f16" (conv16_f16 / conv_dma<_Float16>: 32 x 16 tiles for every layer).  Transposed convolutions: K = Cin, 4*Cout
+    GEMM columns; fp32: conv_dma<float, 8, 128, ...> on 8 x 16 tiles of input pixels, fp16: convt16_f16 on 16 x 16 tiles.  The
+    first (Cin = 1) and last (1x1, Cout = 1) layers do not use the matrix cores: 0."""
     kind = launch["kind"]
     if kind in ("first", "out"):
         return 0.0
     cin, cout, h, w = launch["cin"], launch["cout"], launch["h"], launch["w"]
     if kind == "convt":
-        return 2.0 * cin * 4 * cout * _ceil_to(h, 8) * _ceil_to(w, 16)
+        return 2.0 * cin * 4 * cout * _ceil_to(h, 16 if algo == "direct_f16" else 8) * _ceil_to(w, 16)
     if algo == "winograd":
         if winograd_tile(launch, wino_mode) == 4:
             return 4.5 * cin * cout * _wino4_computed_area(h, w, launch.get("epi", "plain"))

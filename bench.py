@@ -221,7 +221,7 @@ def forward_summary(ms_mean, b, algo, peak, wino_mode="auto"):
     """All 23 launches.  `executed_mfma_tflops` / `frac_mfma_peak_executed` cover the launches that run on the matrix pipe `peak`
     belongs to (fp32 path: the 3x3 layers, and the transposed convolutions only when they run the exact-fp32 form); the
     split-bf16 transposed convolutions are summarised under `convt` against the bf16 peak."""
-    from audiodenoiser_amd.roofline import PEAK_HBM_GBS, PEAK_MFMA_F16_TFLOPS, executed_mfma_flops, unet_launches
+    from audiodenoiser_amd.roofline import ACHIEVABLE_HBM_GBS, PEAK_HBM_GBS, PEAK_MFMA_F16_TFLOPS, executed_mfma_flops, unet_launches
     launches = unet_launches(F_BINS, T_FRAMES)
     f16 = algo == "direct_f16"
     half = 0.5 if f16 else 1.0
@@ -240,14 +240,37 @@ def forward_summary(ms_mean, b, algo, peak, wino_mode="auto"):
            "executed_mfma_basis": f"{len(on_pipe)} launches on this matrix pipe, {round(pipe_ms, 3)} ms of the forward",
            "algorithmic_GBps": round(tot_bytes / (fwd_ms * 1e-3) / 1e9, 1),
            "frac_hbm_peak": round(tot_bytes / (fwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+           "frac_hbm_achievable": round(tot_bytes / (fwd_ms * 1e-3) / 1e9 / ACHIEVABLE_HBM_GBS, 4),
            "per_launch_ms": {l["name"]: round(float(m), 4) for l, m in zip(launches, ms_mean)}}
+    # per launch: fraction of the matrix pipe's peak the launch EXECUTES at (padded tiles counted; the split-bf16 transposed
+    # convolutions: six bf16 products against the bf16 peak) and fraction of the HBM roof its algorithmic bytes amount to
+    # (8 TB/s spec / 6.3 TB/s achievable copy rate); a launch fused into its neighbour (~0 ms) is left out
+    plf = {}
+    for i, (l, m) in enumerate(zip(launches, ms_mean)):
+        m = float(m)
+        if m < 0.02:
+            continue
+        by = (l["act_bytes"] * b + l["weight_bytes"]) * half
+        ent = {"hbm": round(by / (m * 1e-3) / 1e9 / PEAK_HBM_GBS, 3), "hbm_achievable": round(by / (m * 1e-3) / 1e9 / ACHIEVABLE_HBM_GBS, 3)}
+        if l["kind"] == "conv3x3":
+            ent["mfma"] = round(executed_mfma_flops(l, algo, wino_mode) * b / (m * 1e-3) / 1e12 / peak, 3)
+        elif l["kind"] == "convt":
+            ex = executed_mfma_flops(l, "direct_f16" if f16 else "direct") * b
+            ent["mfma"] = round(ex * 6.0 / (m * 1e-3) / 1e12 / PEAK_MFMA_F16_TFLOPS, 3) if split else round(ex / (m * 1e-3) / 1e12 / peak, 3)
+        plf[l["name"]] = ent
+    out["per_launch_frac"] = plf
     ct = [i for i, l in enumerate(launches) if l["kind"] == "convt"]
     ct_ms = float(ms_mean[ct].sum())
     ct_alg = sum(launches[i]["flops"] for i in ct) * b
     ct_bytes = sum(launches[i]["act_bytes"] * b + launches[i]["weight_bytes"] for i in ct) * half
     out["convt"] = {"ms": round(ct_ms, 3), "algorithmic_tflops": round(ct_alg / (ct_ms * 1e-3) / 1e12, 2),
                     "algorithmic_GBps": round(ct_bytes / (ct_ms * 1e-3) / 1e9, 1),
-                    "frac_hbm_peak": round(ct_bytes / (ct_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+                    "frac_hbm_peak": round(ct_bytes / (ct_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                    "frac_hbm_achievable": round(ct_bytes / (ct_ms * 1e-3) / 1e9 / ACHIEVABLE_HBM_GBS, 4)}
+    if f16:
+        out["convt"]["kernel"] = ("convt16_f16: v_mfma_f32_16x16x32_f16, items of 256 pixels x 256 columns, ring of four LDS images "
+                                  "(copies three steps ahead), 16-byte stores from the accumulators (v_permlane16_swap)"
+                                  if os.environ.get("ADN_F16_CONVT", "") != "dma" else "conv_dma<_Float16, 8, 128, ..., CONVT2X2>")
     if split:
         ct_exec = sum(executed_mfma_flops(launches[i], "direct") for i in ct) * b * 6.0
         out["convt"].update({
@@ -291,7 +314,9 @@ def bench_stft(dev, clips=10000, length=132300, n_fft=1024, hop=256, steps=20, w
            "clips_per_s": round(clips / (ms * 1e-3), 1), "frames_per_s": round(clips * nfr / (ms * 1e-3), 1),
            "dtype": "f32",
            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
-                        "frac": round(gbs / 8000.0, 4), "traffic": traffic, "traffic_source": source,
+                        "frac": round(gbs / 8000.0, 4), "frac_of_achievable": round(gbs / 6300.0, 4),
+                        "achievable": "6.3 TB/s: the measured float4 copy rate of MI355X_MICROARCH.md (79 % of the spec)",
+                        "traffic": traffic, "traffic_source": source,
                         "kernel": "stft_wave_kernel<512,4,16,3>, 1 launch per step",
                         "algorithmic_bytes_per_launch": clips * bytes_per_clip, "bytes_per_clip": bytes_per_clip}}
     # the same clips straight to the network's input format (wav -> forward flow, BASELINE configs[0] at scale): STFT +
@@ -317,7 +342,8 @@ def bench_stft(dev, clips=10000, length=132300, n_fft=1024, hop=256, steps=20, w
         "kernel": "stft_fit_kernel<512,4,3>: persistent workgroups, 32-frame groups = whole 128-byte output lines, fp16 [bin][frame] image",
         "ms_per_launch": round(ms_fit, 4), "clips_per_s": round(clips / (ms_fit * 1e-3), 1),
         "algorithmic_bytes_per_launch": fit_bytes,
-        "algorithmic_GBps": round(fit_bytes / (ms_fit * 1e-3) / 1e9, 1), "frac_hbm_peak": round(fit_bytes / (ms_fit * 1e-3) / 1e9 / 8000.0, 4)}
+        "algorithmic_GBps": round(fit_bytes / (ms_fit * 1e-3) / 1e9, 1), "frac_hbm_peak": round(fit_bytes / (ms_fit * 1e-3) / 1e9 / 8000.0, 4),
+        "frac_hbm_achievable": round(fit_bytes / (ms_fit * 1e-3) / 1e9 / 6300.0, 4)}
     del fit
     if cpu_clips > 0:
         import oracle

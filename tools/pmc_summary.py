@@ -33,7 +33,7 @@ FAMILIES = {
     "conv16_f16": lambda n: n.startswith("conv16_f16"),
     # transposed convolutions: <T, TH = 8, BN = 128, WM = 2, WN = 2, TAPS = 1, ...> (split-bf16 form: conv_dma<float, 8, 128, 2, 2, 1, 2, 2, 3, 1>)
     "convt_f32": lambda n: n.startswith(("conv_mfma<float", "conv_dma<float")) and ", 8, 128, 2, 2, 1, " in n,
-    "convt_f16": lambda n: n.startswith(("conv_mfma<_Float16", "conv_dma<_Float16")) and ", 8, 128, 2, 2, 1, " in n,
+    "convt_f16": lambda n: (n.startswith(("conv_mfma<_Float16", "conv_dma<_Float16")) and ", 8, 128, 2, 2, 1, " in n) or n.startswith("convt16_f16"),
     "stft_wave_kernel": lambda n: n.startswith("stft_wave_kernel") and not n.rstrip().endswith("true>"),
     "stft_wave_kernel_fit": lambda n: n.startswith("stft_wave_kernel") and n.rstrip().endswith("true>"),
     "stft_fit_kernel": lambda n: n.startswith("stft_fit_kernel"),
@@ -79,7 +79,7 @@ def short(name: str) -> str:
 
 
 def ours(n: str) -> bool:
-    return n.startswith(("conv_", "conv16", "stft", "per_clip", "nhwc", "quantize", "wino", "loss_", "gl_", "istft", "dot_finish"))
+    return n.startswith(("conv_", "conv16", "convt16", "stft", "per_clip", "nhwc", "quantize", "wino", "loss_", "gl_", "istft", "dot_finish"))
 
 
 def read_counter(d, counter):
