@@ -52,6 +52,30 @@ __device__ __forceinline__ float max_nan(float a, float b) { return __builtin_el
 __device__ __forceinline__ float max4_nan(float a, float b, float c, float d) { return max_nan(max_nan(a, b), max_nan(c, d)); }
 #endif
 
+#ifdef __HIPCC__
+// Three-term bf16 split of eight fp32 values (the fp32 transposed convolutions on the bf16 matrix cores: conv_dma<..., SPLIT> in
+// conv_kernels.hip, convt32_kernels.hip): x = hi + mid + lo with round-to-nearest terms, 24 mantissa bits in all.  hi is clamped to
+// the largest finite bf16 so that every FINITE x splits exactly (round-to-nearest would make a bf16 infinity of |x| >= 3.3961e38);
+// x = +-inf gives hi = 3.39e38, mid = +-inf, lo = NaN: non-finite stays non-finite.
+typedef __bf16 adn_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float adn_f32x4 __attribute__((ext_vector_type(4)));
+constexpr float ADN_BF16_MAX_F = 0x1.fep127f;                  // largest finite bf16
+__device__ __forceinline__ void split3_bf16(const adn_f32x4 &x0, const adn_f32x4 &x1, adn_bf16x8 &hi, adn_bf16x8 &mid, adn_bf16x8 &lo)
+{
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = e < 4 ? x0[e] : x1[e - 4];
+        const float hf = __builtin_amdgcn_fmed3f((float)(__bf16)x, -ADN_BF16_MAX_F, ADN_BF16_MAX_F);
+        const float r1 = x - hf;
+        const __bf16 m = (__bf16)r1;
+        const float r2 = r1 - (float)m;
+        hi[e] = (__bf16)hf;
+        mid[e] = m;
+        lo[e] = (__bf16)r2;
+    }
+}
+#endif
+
 // One activation source of a convolution (fp32 or fp16 storage, decided by the launcher).  (offY, offX) is
 // the zero-pad placed above / left of the tensor when it is aligned to the output domain (UpSampleLayer's F.pad,
 // reference model.py:44-47).
@@ -162,6 +186,11 @@ hipError_t launch_conv16(ConvKind kind, const ConvArgs &a, bool resident, hipStr
 // layer's Cout biases (plain), N / H / W = the INPUT's
 bool convt16_applicable(const ConvArgs &a);
 hipError_t launch_convt16(const ConvArgs &a, hipStream_t st);
+
+// fp32 transposed convolutions on v_mfma_f32_16x16x32_bf16 with the three-term split of both operands (convt32_kernels.hip): the
+// structure of convt16_f16; weights from ConvArgs::wpk in pack_convt32 layout, ConvArgs::bias = the layer's Cout biases (plain)
+bool convt32_applicable(const ConvArgs &a);
+hipError_t launch_convt32(const ConvArgs &a, hipStream_t st);
 
 // First layer: Conv2d(1 -> 64, 3x3, pad 1) + folded BN + ReLU, fp32 input, blocked-layout output.  w9x64: [tap][cout].
 hipError_t launch_conv_first(const float *x, const float *w9x64, const float *bias, void *out, bool f16,

@@ -504,22 +504,7 @@ struct DmaCfg {
 // -inf / NaN although x is finite; hi is therefore clamped to the largest finite bf16 (3.3895e38, one v_med3_f32): every FINITE
 // operand splits exactly.  Non-finite operands stay non-finite but not bit-compatible: x = +-inf gives hi = 3.39e38, mid = +-inf,
 // lo = NaN, so the sum is NaN where the exact-fp32 form may give +-inf (tests: test_convt_split_extreme_operands).
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr float BF16_MAX_F = 0x1.fep127f;                  // largest finite bf16
-__device__ __forceinline__ void split3_bf16(const f32x4 &x0, const f32x4 &x1, bf16x8 &hi, bf16x8 &mid, bf16x8 &lo)
-{
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const float x = e < 4 ? x0[e] : x1[e - 4];
-        const float hf = __builtin_amdgcn_fmed3f((float)(__bf16)x, -BF16_MAX_F, BF16_MAX_F);
-        const float r1 = x - hf;
-        const __bf16 m = (__bf16)r1;
-        const float r2 = r1 - (float)m;
-        hi[e] = (__bf16)hf;
-        mid[e] = m;
-        lo[e] = (__bf16)r2;
-    }
-}
+typedef adn_bf16x8 bf16x8;
 
 template <typename T, int TH, int BN, int WM, int WN, int TAPS, int KG, int EPI, int WPE, int SPLIT = 0>
 __global__ __launch_bounds__(64 * WM * WN, WPE) void conv_dma(const ConvArgs p)
