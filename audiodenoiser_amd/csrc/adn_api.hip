@@ -80,7 +80,7 @@ struct Conv3x3Layer {
 struct ConvTLayer {
     int Cin, Cout;
     size_t w_off, b_off;
-    size_t w16_off, braw_off;   // pack_convt16 (fp16: convt16_f16) / pack_convt32 (fp32: convt32_bf16) form of the weights, 0 = none; the Cout biases as they are
+    size_t w16_off, braw_off;   // fp16 path: pack_convt16 form of the weights (convt16_f16), 0 = none; the Cout biases as they are
 };
 
 }  // namespace
@@ -113,9 +113,6 @@ struct adn_unet {
     // accumulation; conv_dma<..., SPLIT>): fp32-level accuracy at 3/8 of the exact-fp32 matrix time.  ADN_CONVT_SPLIT=0 when the
     // handle is created keeps the exact-fp32 MFMA form.
     bool convt_split = true;
-    // ... in the convt16_f16 structure (convt32_bf16: 16x16x32 MFMA, persistent, ring of LDS images, 16-byte stores from the
-    // accumulators); ADN_CONVT_SPLIT=dma keeps the split on conv_dma<float, ..., SPLIT> (rounds 3-4)
-    bool convt_ring = true;
     // Small grids (one or a few clips): a 3x3 layer whose F(4x4,3x3) launch would be fewer than `auto_grid` workgroups (2 per CU)
     // runs on the finer-grained F(2x2,3x3) kernel instead, cut along K where even that grid cannot fill the chip
     // (choose_algo below).  The choice then depends on the batch size, so the same clip computed alone or inside a large batch
@@ -345,34 +342,6 @@ void pack_convt_split(const float *w /*(Cin,Cout,2,2)*/, int Cin, int Cout, uint
                             dst[o++] = plane == 0 ? hi : plane == 1 ? mid : bf16_rne(r2);
                         }
                     }
-}
-
-// Split-bf16 weights for convt32_bf16 (convt32_kernels.hip): columns in pairs as pack_convt16; per column block and chunk of 16
-// channels TWO MFMA A-fragments of K = 32 = two term halves of 16 channels: Fa = [hi | mid], Fb = [lo | hi]
-// [column tile][chunk][column block cb][fragment][k group g][column % 16][8 bf16]: k groups 0, 1 = first half (channels chunk*16 + 8g + e),
-// k groups 2, 3 = second half (the same channels, 8 (g - 2) + e).  Terms as pack_convt_split (round to nearest, leading term clamped).
-void pack_convt32(const float *w /*(Cin,Cout,2,2)*/, int Cin, int Cout, uint16_t *dst)
-{
-    const int nchunk = Cin / 16, npair = Cout / 16, nct = Cout / 64;
-    for (int ct = 0; ct < nct; ++ct)
-        for (int ch = 0; ch < nchunk; ++ch)
-            for (int cb = 0; cb < 16; ++cb) {
-                const int P = ct * 8 + (cb >> 1), dj = cb & 1, di = P / npair, cg = P % npair;
-                for (int g = 0; g < 4; ++g)
-                    for (int c16 = 0; c16 < 16; ++c16)
-                        for (int e = 0; e < 8; ++e) {
-                            const int ci = ch * 16 + 8 * (g & 1) + e, co = cg * 16 + c16;
-                            const float v = w[(((size_t)ci * Cout + co) * 2 + di) * 2 + dj];
-                            uint16_t hi = bf16_rne(v);
-                            if ((hi & 0x7fffu) == 0x7f80u && std::isfinite(v)) hi = (uint16_t)((hi & 0x8000u) | 0x7f7fu);
-                            const float r1 = v - bf16_to_float(hi);
-                            const uint16_t mid = bf16_rne(r1);
-                            const uint16_t lo = bf16_rne(r1 - bf16_to_float(mid));
-                            const size_t base = ((((size_t)ct * nchunk + ch) * 16 + cb) * 2) * 512;      // 2 fragments x 64 lanes x 8
-                            dst[base + (size_t)(g * 16 + c16) * 8 + e] = g < 2 ? hi : mid;              // Fa = [hi | mid]
-                            dst[base + 512 + (size_t)(g * 16 + c16) * 8 + e] = g < 2 ? lo : hi;         // Fb = [lo | hi]
-                        }
-            }
 }
 
 struct Plan {
@@ -669,15 +638,12 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
         t.nwg_total = 0;
         ADN_MARK();
         bool t16 = false;
-        if (TL.w16_off) {                                // convt16_f16 (fp16) / convt32_bf16 (fp32) wherever they apply
+        if (f16 && TL.w16_off) {                         // fp16: convt16_f16 wherever it applies (convt16_kernels.hip)
             adn::ConvArgs t2 = t;
             t2.wpk = h->dev + TL.w16_off;
             t2.bias = h->dev + TL.braw_off;
-            if (f16 && adn::convt16_applicable(t2)) {
+            if (adn::convt16_applicable(t2)) {
                 ADN_HIP(adn::launch_convt16(t2, st));
-                t16 = true;
-            } else if (!f16 && adn::convt32_applicable(t2)) {
-                ADN_HIP(adn::launch_convt32(t2, st));
                 t16 = true;
             }
         }
@@ -829,10 +795,7 @@ int adn_unet_create_general(adn_unet **handle, int device, const float *const *t
         h->use_wino = std::strcmp(algo, "direct") != 0;
     if (h->f16) h->use_wino = false;                           // the fp16 path runs the direct fp16-MFMA kernels
     if (const char *sk = std::getenv("ADN_WINO_SPLITK")) h->allow_split = std::atoi(sk) != 0;
-    if (const char *cs = std::getenv("ADN_CONVT_SPLIT")) {
-        h->convt_ring = std::strcmp(cs, "dma") != 0;
-        h->convt_split = !h->convt_ring || std::atoi(cs) != 0;
-    }
+    if (const char *cs = std::getenv("ADN_CONVT_SPLIT")) h->convt_split = std::atoi(cs) != 0;
     if (const char *bi = std::getenv("ADN_BATCH_INVARIANT")) h->batch_invariant = std::atoi(bi) != 0;
     if (const char *ff = std::getenv("ADN_F16_FIRST")) h->f16_fuse_first = std::atoi(ff) != 0;
     if (const char *fc = std::getenv("ADN_F16_CONV")) h->f16_conv = std::atoi(fc) == 32 ? 0 : 1;
@@ -920,12 +883,6 @@ int adn_unet_create_general(adn_unet **handle, int device, const float *const *t
         } else if (h->convt_split) {
             TL.w_off = reserve(((size_t)3 * 4 * cin * co + 1) / 2);          // three bf16 planes
             pack_convt_split(t[ti], cin, co, reinterpret_cast<uint16_t *>(host.data() + TL.w_off));
-            if (h->convt_ring && cin % 16 == 0 && cin >= 32 && co % 64 == 0) {
-                TL.w16_off = reserve((size_t)8 * cin * co);                  // four bf16 planes' worth: Fa = [hi | mid], Fb = [lo | hi]
-                pack_convt32(t[ti], cin, co, reinterpret_cast<uint16_t *>(host.data() + TL.w16_off));
-                TL.braw_off = reserve(co);
-                std::memcpy(host.data() + TL.braw_off, t[ti + 1], sizeof(float) * co);
-            }
         } else {
             TL.w_off = reserve((size_t)4 * cin * co);
             pack_convt<float>(t[ti], cin, co, host.data() + TL.w_off);

@@ -54,7 +54,7 @@ __device__ __forceinline__ float max4_nan(float a, float b, float c, float d) { 
 
 #ifdef __HIPCC__
 // Three-term bf16 split of eight fp32 values (the fp32 transposed convolutions on the bf16 matrix cores: conv_dma<..., SPLIT> in
-// conv_kernels.hip, convt32_kernels.hip): x = hi + mid + lo with round-to-nearest terms, 24 mantissa bits in all.  hi is clamped to
+// conv_kernels.hip): x = hi + mid + lo with round-to-nearest terms, 24 mantissa bits in all.  hi is clamped to
 // the largest finite bf16 so that every FINITE x splits exactly (round-to-nearest would make a bf16 infinity of |x| >= 3.3961e38);
 // x = +-inf gives hi = 3.39e38, mid = +-inf, lo = NaN: non-finite stays non-finite.
 typedef __bf16 adn_bf16x8 __attribute__((ext_vector_type(8)));
@@ -186,11 +186,6 @@ hipError_t launch_conv16(ConvKind kind, const ConvArgs &a, bool resident, hipStr
 // layer's Cout biases (plain), N / H / W = the INPUT's
 bool convt16_applicable(const ConvArgs &a);
 hipError_t launch_convt16(const ConvArgs &a, hipStream_t st);
-
-// fp32 transposed convolutions on v_mfma_f32_16x16x32_bf16 with the three-term split of both operands (convt32_kernels.hip): the
-// structure of convt16_f16; weights from ConvArgs::wpk in pack_convt32 layout, ConvArgs::bias = the layer's Cout biases (plain)
-bool convt32_applicable(const ConvArgs &a);
-hipError_t launch_convt32(const ConvArgs &a, hipStream_t st);
 
 // First layer: Conv2d(1 -> 64, 3x3, pad 1) + folded BN + ReLU, fp32 input, blocked-layout output.  w9x64: [tap][cout].
 hipError_t launch_conv_first(const float *x, const float *w9x64, const float *bias, void *out, bool f16,

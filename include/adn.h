@@ -194,8 +194,7 @@ ADN_API int adn_istft(const float *spec, int n_clips, int n_frames, int n_fft, i
  *   ADN_WINO_SPLITK=1        fp32: split-K wherever the F(2x2,3x3) grid cannot fill the chip (default: only by the small-grid rule)
  *   ADN_BATCH_INVARIANT=1    initial value of adn_unet_set_batch_invariant (above)
  *   ADN_AUTO_GRID=n, ADN_AUTO_GRID64=n   thresholds of the small-grid rule in F(4x4,3x3) workgroups (192 / 512; tools/small_grid_probe.py)
- *   ADN_CONVT_SPLIT=0 | dma  fp32 transposed convolutions on the exact-fp32 MFMA instead of the three-term bf16 split | the split on
- *                            conv_dma<float, ..., SPLIT> (32x32x16 MFMA, LDS-staged stores) instead of convt32_bf16
+ *   ADN_CONVT_SPLIT=0        fp32 transposed convolutions on the exact-fp32 MFMA instead of the three-term bf16 split
  *   ADN_F16_CONV=32          fp16 3x3 layers on conv_dma<_Float16> (32x32x16 MFMA) instead of conv16_f16 (16x16x32)
  *   ADN_F16_FIRST=0          fp16: Conv2d(1 -> 64) as its own launch instead of fused into down1's second convolution
  *   ADN_F16_CONVT=dma        fp16 transposed convolutions on conv_dma<_Float16> (32x32x16 MFMA, LDS-staged stores) instead of convt16_f16

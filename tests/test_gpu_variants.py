@@ -27,7 +27,6 @@ MODES = {
     "direct": {"ADN_CONV_ALGO": "direct"},
     "splitk": {"ADN_WINO_SPLITK": "1"},
     "convt_exact": {"ADN_CONVT_SPLIT": "0"},
-    "convt_dma": {"ADN_CONVT_SPLIT": "dma"},
 }
 ENV_KEYS = ("ADN_BATCH_INVARIANT", "ADN_WINO_TILE", "ADN_CONV_ALGO", "ADN_WINO_SPLITK", "ADN_CONVT_SPLIT")
 
@@ -128,7 +127,7 @@ def test_fp16_path_reports_overflow_as_non_finite_not_garbage(dev, golden_dir, v
 NONFINITE_SHAPES = ((257, 188), (513, 256), (1100, 48))
 NONFINITE_POS = {(257, 188): (20, 20), (513, 256): (60, 40), (1100, 48): (40, 20)}
 LAYER_WEIGHT = 92
-EXTRA = {"default": 3, "batch_invariant": 3, "f2x2": 1, "f4x4_forced": 3, "direct": 0, "splitk": 3, "convt_exact": 3, "convt_dma": 3, "f16": 0}
+EXTRA = {"default": 3, "batch_invariant": 3, "f2x2": 1, "f4x4_forced": 3, "direct": 0, "splitk": 3, "convt_exact": 3, "f16": 0}
 
 
 def _nonfinite_input(f, t, kind):
