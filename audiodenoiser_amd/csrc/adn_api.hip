@@ -770,8 +770,8 @@ int adn_unet_create_general(adn_unet **handle, int device, const float *const *t
                             int num_classes)
 {
     if (!handle || !t) return fail(ADN_ERR_INVALID, "adn_unet_create: null argument");
-    if (in_channels < 1 || in_channels > 15 || num_classes < 1 || num_classes > 64)
-        return fail(ADN_ERR_INVALID, "adn_unet_create_general: need 1 <= in_channels <= 15 and 1 <= num_classes <= 64");
+    if (in_channels < 1 || in_channels > 64 || num_classes < 1 || num_classes > 64)
+        return fail(ADN_ERR_INVALID, "adn_unet_create_general: need 1 <= in_channels <= 64 and 1 <= num_classes <= 64");
     if (dtype != ADN_DTYPE_F32 && dtype != ADN_DTYPE_F16) return fail(ADN_ERR_INVALID, "adn_unet_create: dtype must be ADN_DTYPE_F32 or ADN_DTYPE_F16");
     if (n_tensors != ADN_N_WEIGHT_TENSORS) return fail(ADN_ERR_INVALID, "adn_unet_create: expected 118 tensors");
     for (int i = 0; i < n_tensors; ++i)

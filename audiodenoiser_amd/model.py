@@ -70,8 +70,8 @@ class UpSampleLayer(_ParamsOnly):
 class UNet(nn.Module):
     def __init__(self, in_channels: int = 1, num_classes: int = 1):
         super().__init__()
-        if not (1 <= in_channels <= 15 and 1 <= num_classes <= 64):
-            raise ValueError("UNet(in_channels, num_classes): the MI355X path takes 1..15 input planes and 1..64 classes "
+        if not (1 <= in_channels <= 64 and 1 <= num_classes <= 64):
+            raise ValueError("UNet(in_channels, num_classes): the MI355X path takes 1..64 input planes and 1..64 classes "
                              "(reference configuration: UNet(1, 1), test.py:63)")
         self.in_channels, self.num_classes = in_channels, num_classes
         for (name, cin, cout) in DOUBLE_CONVS:

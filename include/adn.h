@@ -86,7 +86,7 @@ ADN_API int adn_unet_create(adn_unet **handle, int device, const float *const *h
 ADN_API int adn_unet_create_ex(adn_unet **handle, int device, const float *const *host_tensors, int n_tensors, int dtype);
 /* UNet(in_channels, num_classes) as the reference declares it (code/model.py:54,56,68; its own callers use (1, 1), test.py:63):
  * the same 118 tensors with downconv1.conv.double_conv.0.weight (64, in_channels, 3, 3), out.weight (num_classes, 64, 1, 1) and
- * out.bias (num_classes).  x is then (N, in_channels, F, T) and y (N, num_classes, F, T), both NCHW fp32.  1 <= in_channels <= 15,
+ * out.bias (num_classes).  x is then (N, in_channels, F, T) and y (N, num_classes, F, T), both NCHW fp32.  1 <= in_channels <= 64,
  * 1 <= num_classes <= 64.  With more than one input plane / class the first / last
  * convolution run as their own launches (the fused forms are for one plane / one class). */
 ADN_API int adn_unet_create_general(adn_unet **handle, int device, const float *const *host_tensors, int n_tensors, int dtype,

@@ -57,6 +57,19 @@ def test_many_input_planes_on_a_long_clip(dev, dtype, tol):
     assert y.shape == ref.shape and _rel(y, ref) <= tol
 
 
+def test_twenty_input_planes(dev):
+    """UNet(in_channels=20, num_classes=2): beyond the 15 planes the first layer's input window was limited to through round 4."""
+    from oracle import unet_torch
+    from audiodenoiser_amd.weights import make_input, make_state_dict
+    sd = make_state_dict(1234, 20, 2)
+    x = make_input(13, 20, 40, 56).reshape(1, 20, 40, 56)
+    ref = unet_torch.unet_forward(unet_torch.to_torch_state(sd), torch.from_numpy(x)).numpy()
+    for dtype, tol in (("f32", 1e-4), ("f16", 1e-2)):
+        with torch.no_grad():
+            y = _net(sd, dev, dtype, 20, 2)(torch.from_numpy(x).to(dev)).cpu().numpy()
+        assert y.shape == ref.shape and _rel(y, ref) <= tol, dtype
+
+
 # (F, T), dtype: 4100^2 > 2^24 pixels (the old bound: a 64-channel fp32 image of 4.3 GB, beyond one buffer descriptor);
 # 6704^2 = 44.9 M pixels: beyond conv16_f16's 32-bit output offsets (the fp16 path falls back to conv_dma<_Float16> and the unfused
 # first layer) and a 1.4 GB channel block; 11584^2 = 134.19 M pixels: just below 2^27, channel blocks of 4.29 GB -- byte offsets up

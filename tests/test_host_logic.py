@@ -76,7 +76,7 @@ def test_model_parameter_tree_and_guards(weights_np):
     with torch.no_grad(), pytest.raises(RuntimeError, match="ROCm device"):
         m(torch.zeros(1, 1, 16, 16))
     with pytest.raises(ValueError):
-        UNet(16, 1)                                       # 1..15 input planes, 1..64 classes
+        UNet(65, 1)                                       # 1..64 input planes, 1..64 classes
     with pytest.raises(ValueError):
         UNet(1, 0)
     # UNet(in_channels, num_classes) as the reference declares it (model.py:54,56,68): same 136 keys, two shapes differ
@@ -609,3 +609,20 @@ def test_library_digest_identifies_code_not_comments(tmp_path, monkeypatch):
     assert B._digest() == d0 and B._raw_digest() != r0        # any edit rebuilds; only code edits orphan the PMC profile
     (csrc / "k.hip").write_text("__global__ void k(float *p) { p[0] = 2.f; }\n")
     assert B._digest() != d0
+
+
+def test_library_sources_carry_no_experiment_switches():
+    """Source hygiene: the production sources contain no timing-experiment code and read the environment only
+    where a U-Net handle is created -- the switches listed in the table of include/adn.h, nothing else."""
+    import glob
+    csrc = os.path.join(ROOT, "audiodenoiser_amd", "csrc")
+    header = open(os.path.join(ROOT, "include", "adn.h")).read()
+    documented = set(re.findall(r"\b(ADN_[A-Z0-9_]+)=", header[header.index("environment switches"):]))
+    read = {}
+    for path in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))):
+        text = open(path).read()
+        assert "ADN_EXPERIMENTS" not in text, path
+        for name in re.findall(r'getenv\("([A-Z0-9_]+)"\)', text):
+            read.setdefault(name, set()).add(os.path.basename(path))
+    assert set().union(*read.values()) == {"adn_api.hip"}, read
+    assert set(read) == documented, sorted(set(read) ^ documented)
