@@ -72,6 +72,11 @@ __device__ __forceinline__ T16Item t16_decode(const ConvArgs &p, int id)
     return it;
 }
 
+// NT: the item holds ALL columns of the layer (nct == 1: up4, Cout = 64), i.e. every input byte is read exactly once by one CU and the
+// kernel is HBM-bound on its output: input copies and output stores then carry the non-temporal hint.  Measured per batch-256 launch
+// (profiles/r05_convt16_nt_ab.txt): up4 1.208 -> 1.110 ms; on the layers whose input is re-read by other column tiles the hinted
+// stores cost 5 % (up3 0.681 -> 0.714 ms), so they keep the default policy.
+template <bool NT>
 __global__ __launch_bounds__(T16_NT, 2) void convt16_f16(const ConvArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -121,8 +126,9 @@ __global__ __launch_bounds__(T16_NT, 2) void convt16_f16(const ConvArgs p)
             const unsigned long long ab = a0 + (unsigned long long)b * xblk;
             const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ab);
             const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ab >> 32));
-            dma16_buf(dma_rsrc(reinterpret_cast<const void *>(((unsigned long long)hi << 32) | lo), xblk), xoff | kill, 0u,
-                      reinterpret_cast<float *>(img + b * (T16_X_BYTES / 2) + wave * 1024));
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(dma_rsrc(reinterpret_cast<const void *>(((unsigned long long)hi << 32) | lo), xblk),
+                                                     (__attribute__((address_space(3))) void *)(img + b * (T16_X_BYTES / 2) + wave * 1024), 16,
+                                                     xoff | kill, 0u, 0, NT ? 2 : 0);
         }
         const unsigned wsoff = (unsigned)__builtin_amdgcn_readfirstlane((fi.ct * nchunk + f_chunk) * T16_W_BYTES);
 #pragma unroll
@@ -209,7 +215,7 @@ __global__ __launch_bounds__(T16_NT, 2) void convt16_f16(const ConvArgs p)
                     const int gy = gy0 + i;
                     const unsigned off = ((gy < H) & (gx < W))
                                              ? (unsigned)((2 * gy + di) * Wo + 2 * gx + (g & 1)) * 32u + (unsigned)((g >> 1) * 16) : ADN_DMA_OOB;
-                    __builtin_amdgcn_raw_buffer_store_b128(v, ors, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(v, ors, off, 0, NT ? 2 : 0);
                     // (gfx950 / hipcc 7.2: a 16-byte store's data registers must not be rewritten by the next VALU instruction --
                     // profiles/NOTES.md, round 4, "store-data hazard"; the wait state is tied to the registers)
                     asm volatile("s_nop 1" : "+v"(v));
@@ -284,11 +290,13 @@ hipError_t launch_convt16(const ConvArgs &a, hipStream_t st)
     static std::atomic<unsigned long long> attr_mask{0};
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(attr_mask.load(std::memory_order_acquire) & bit)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(convt16_f16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T16_LDS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(convt16_f16<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T16_LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(convt16_f16<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T16_LDS);
         if (e != hipSuccess) return e;
         attr_mask.fetch_or(bit, std::memory_order_release);
     }
-    hipLaunchKernelGGL(convt16_f16, dim3((unsigned)grid), dim3(T16_NT), T16_LDS, st, a2);
+    if (a2.nct == 1) hipLaunchKernelGGL(convt16_f16<true>, dim3((unsigned)grid), dim3(T16_NT), T16_LDS, st, a2);
+    else hipLaunchKernelGGL(convt16_f16<false>, dim3((unsigned)grid), dim3(T16_NT), T16_LDS, st, a2);
     return hipGetLastError();
 }
 

@@ -16,7 +16,7 @@ run() {
 import json, sys
 d = json.loads(sys.stdin.read().strip().splitlines()[-1]); f = d['f16']; t = f['forward']['per_launch_ms']
 keys = ('down1.conv2+pool', 'down2.conv1', 'down2.conv2+pool', 'down3.conv1', 'bottleneck.conv2', 'up1.conv1(cat)', 'up3.conv1(cat)', 'up3.conv2', 'up4.conv1(cat)', 'up4.conv2')
-print('%-12s f16 %.3f ms/step | %s' % ('$v', f['ms_per_step'], ' '.join('%.3f' % t[k] for k in keys)))" >> $out
+print('%-12s f16 %.3f ms/step | %s | convT %s' % ('$v', f['ms_per_step'], ' '.join('%.3f' % t[k] for k in keys), ' '.join('%.3f' % t['up%d.convT' % i] for i in (1, 2, 3, 4))))" >> $out
 }
 for rep in $(seq 1 $REPS); do
   for v in "$@"; do run $v; done
