@@ -875,9 +875,16 @@ def test_end_to_end_test_script_mirror(dev, tmp_path):
 
 
 @pytest.mark.gpu
-def test_forward_is_stream_capturable(net, dev):
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_forward_is_stream_capturable(net, weights_np, dev, dtype):
     """The launch sequence only enqueues on the caller's stream (no allocation, no synchronisation), so it can be
-    captured into a HIP graph and replayed — what a serving loop does to drop the 23 launch overheads at batch 1."""
+    captured into a HIP graph and replayed — what a serving loop does to drop the 23 launch overheads at batch 1.
+    Both arithmetic types (fp16: the persistent conv16_f16 / convt16_f16 kernels)."""
+    if dtype == "f16":
+        from audiodenoiser_amd.model import UNet
+        net = UNet(1, 1)
+        net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in weights_np.items()}, strict=True)
+        net = net.to(dev).eval().set_compute_dtype("f16")
     x = torch.rand((1, 1, 64, 48), device=dev) * 3
     with torch.no_grad():
         ref = net(x).clone()                       # warm-up: packs weights, sizes the workspace
