@@ -73,16 +73,22 @@ def test_twenty_input_planes(dev):
 # (F, T), dtype: 4100^2 > 2^24 pixels (the old bound: a 64-channel fp32 image of 4.3 GB, beyond one buffer descriptor);
 # 6704^2 = 44.9 M pixels: beyond conv16_f16's 32-bit output offsets (the fp16 path falls back to conv_dma<_Float16> and the unfused
 # first layer) and a 1.4 GB channel block; 11584^2 = 134.19 M pixels: just below 2^27, channel blocks of 4.29 GB -- byte offsets up
-# to 2^32 - 2^20.  Workspace: 1.1 KB per pixel in fp32 (149 GB for the largest), half of it in fp16.
+# to 2^32 - 2^20; 1 100 000 x 16: a 64-channel image of 4.5 GB only 16 pixels wide -- too large for wino4_conv_f32's pair mode (two
+# clips through one descriptor), also with F(4x4,3x3) forced on every layer ("f32:f4").  Workspace: 1.1 KB per pixel in fp32 (149 GB
+# for the largest), half of it in fp16.
 BIG = [((4100, 4100), "f32"), ((4100, 4100), "f16"), ((6704, 6704), "f32"), ((6704, 6704), "f16"), ((11584, 11584), "f16"),
-       ((11584, 11584), "f32"), ((48, 2796000), "f32")]
+       ((11584, 11584), "f32"), ((48, 2796000), "f32"), ((1100000, 16), "f32"), ((1100000, 16), "f32:f4")]
 WIN, MARGIN = 608, 96
 
 
 @pytest.mark.parametrize("shape,dtype", BIG)
-def test_images_beyond_one_buffer_descriptor(dev, weights_np, shape, dtype):
+def test_images_beyond_one_buffer_descriptor(dev, weights_np, shape, dtype, monkeypatch):
     from oracle import unet_torch
     f, t = shape
+    monkeypatch.delenv("ADN_WINO_TILE", raising=False)
+    if dtype.endswith(":f4"):
+        dtype = dtype.split(":")[0]
+        monkeypatch.setenv("ADN_WINO_TILE", "4")
     tol = 1e-4 if dtype == "f32" else 1e-2
     need = f * t * (1112 if dtype == "f32" else 560) + 3 * f * t * 4
     free = torch.cuda.mem_get_info(dev)[0]
