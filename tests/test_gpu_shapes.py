@@ -81,7 +81,7 @@ BIG = [((4100, 4100), "f32"), ((4100, 4100), "f16"), ((6704, 6704), "f32"), ((67
 WIN, MARGIN = 608, 96
 
 
-@pytest.mark.parametrize("shape,dtype", BIG)
+@pytest.mark.parametrize("shape,dtype", BIG, ids=[f"{s[0]}x{s[1]}-{d.replace(':', '-')}" for s, d in BIG])
 def test_images_beyond_one_buffer_descriptor(dev, weights_np, shape, dtype, monkeypatch):
     from oracle import unet_torch
     f, t = shape
