@@ -39,6 +39,8 @@ Sub-benchmarks in the same JSON line (rank 0, N = 1 only; --no-extras skips them
           explicit serving switches.
   `e2e_config0`  BASELINE configs[0] as one stream sequence: resident audio -> adn_stft_mag_fit -> adn_unet_forward at batch 1
           and 64, with the oracle chain's CPU time beside it.
+  `host_boundary`  the PCIe-inclusive rates of the headline workload (spectrograms in host memory, as the reference's test.py
+          hands them over): pageable `model(x_cpu)`, pinned on one stream, pinned with the copies on their own streams.
   `stft`  BASELINE configs[2]: 10 000 clips x 132 300 samples, n_fft 1024, hop 256, centred; HBM roofline of
           stft_wave_kernel (algorithmic bytes = audio read once + magnitudes written once = 1 590 084 B per clip),
           with the C oracle's STFT timed beside it.
@@ -693,19 +695,115 @@ def bench_e2e_config0(sd_np, dev, iters=30, with_cpu=True):
     return out
 
 
+def bench_host_boundary(sd_np, dev, batch=64, iters=8):
+    """The PCIe-inclusive rate of the headline workload (never `value`): the reference's own call shape hands the model CPU tensors
+    (test.py:100-113), so a drop-in caller that keeps its spectrograms in host memory pays the two copies.  Three forms, batch 64 x
+    513x256 fp32 (33.6 MB each way): (a) `model(x_cpu)` exactly as test.py calls it (pageable memory, wall clock), (b) pinned buffers,
+    copy in -> forward -> copy out on one stream, (c) the same with the copies on their own streams, double buffered, so that batch
+    i+1 goes in and batch i-1 comes out under batch i's forward.  Plus (d) audio in host memory -> adn_stft_mag_fit -> forward ->
+    magnitudes out (configs[0]'s flow; 33.9 MB of audio per 64 clips)."""
+    from audiodenoiser_amd.stft import prepare, stft_magnitude_fit
+    net = make_net(sd_np, dev, "f32")
+    prepare(dev, 1024)
+    shape = (batch, 1, F_BINS, T_FRAMES)
+    gen = torch.Generator().manual_seed(0)
+    x_page = torch.rand(shape, generator=gen) * 4.0
+    x_pin = x_page.clone().pin_memory()
+    y_pin = [torch.empty(shape).pin_memory() for _ in range(2)]
+    a_pin = (torch.rand((batch, 132300), generator=gen) * 2 - 1).pin_memory()
+    mb = x_page.numel() * 4 / 1e6
+    out = {"what": f"batch {batch} x {F_BINS}x{T_FRAMES} fp32 with the spectrograms in HOST memory ({mb:.1f} MB in, {mb:.1f} MB out per "
+                   "batch): what a caller that keeps the reference's CPU-tensor call shape gets; `value` of this line is measured with "
+                   "resident inputs"}
+
+    def rate(ms):
+        return {"ms_per_batch": round(ms, 3), "frames_per_s": round(batch * T_FRAMES / (ms * 1e-3), 1)}
+    with torch.no_grad():
+        for _ in range(2):
+            y = net(x_page)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            y = net(x_page)
+        assert not y.is_cuda
+        out["reference_call_shape_pageable"] = rate((time.perf_counter() - t0) / iters * 1e3)
+
+        comp = torch.cuda.current_stream(dev)
+        xd = [torch.empty(shape, device=dev) for _ in range(2)]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for timed in (False, True):
+            if timed:
+                torch.cuda.synchronize(dev)
+                e0.record()
+            for _ in range(iters if timed else 2):
+                xd[0].copy_(x_pin, non_blocking=True)
+                y = net(xd[0])
+                y_pin[0].copy_(y, non_blocking=True)
+            e1.record()
+        torch.cuda.synchronize(dev)
+        out["pinned_one_stream"] = rate(e0.elapsed_time(e1) / iters)
+
+        s_in, s_out = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        ev_in = [torch.cuda.Event() for _ in range(2)]
+        ev_comp = [torch.cuda.Event() for _ in range(2)]
+        n_it = 2 * iters
+        torch.cuda.synchronize(dev)
+        e0.record()
+        for i in range(n_it):
+            k = i & 1
+            with torch.cuda.stream(s_in):
+                if i >= 2:
+                    s_in.wait_event(ev_comp[k])            # batch i-2's forward has read xd[k]
+                xd[k].copy_(x_pin, non_blocking=True)
+                ev_in[k].record(s_in)
+            comp.wait_event(ev_in[k])
+            y = net(xd[k])
+            ev_comp[k].record(comp)
+            with torch.cuda.stream(s_out):
+                s_out.wait_event(ev_comp[k])
+                y_pin[k].copy_(y, non_blocking=True)
+                y.record_stream(s_out)
+        comp.wait_stream(s_out)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        out["pinned_copy_streams_double_buffered"] = rate(e0.elapsed_time(e1) / n_it)
+        assert bool(torch.isfinite(y_pin[0]).all()) and bool(torch.isfinite(y_pin[1]).all())
+
+        ad = torch.empty(a_pin.shape, device=dev)
+        for timed in (False, True):
+            if timed:
+                torch.cuda.synchronize(dev)
+                e0.record()
+            for _ in range(iters if timed else 2):
+                ad.copy_(a_pin, non_blocking=True)
+                y = net(stft_magnitude_fit(ad, (F_BINS, T_FRAMES), 1024, 256, True))
+                y_pin[0].copy_(y, non_blocking=True)
+            e1.record()
+        torch.cuda.synchronize(dev)
+        out["audio_in_pinned_one_stream"] = rate(e0.elapsed_time(e1) / iters)
+    del xd, ad, y
+    net._release()
+    torch.cuda.empty_cache()
+    return out
+
+
 def per_gpu_reference():
-    """fp32_b256 of the last recorded N = 1 line (profiles/r04_bench.json) if it was taken with this very build: the one-GPU
+    """fp32_b256 of the newest recorded N = 1 line (profiles/rNN_bench.json) that was taken with this very build: the one-GPU
     figure at 256 clips per GPU that an N > 1 value is to be divided by (the N = 1 headline runs 64 clips)."""
-    path = os.path.join(ROOT, "profiles", "r04_bench.json")
-    try:
-        with open(path) as fh:
-            rec = json.load(fh)
-    except (OSError, ValueError):
-        return {"value": None, "note": "no recorded N = 1 line (profiles/r04_bench.json)"}
-    if rec.get("config", {}).get("lib_digest") != lib_digest()[:12] or "fp32_b256" not in rec:
-        return {"value": None, "note": "profiles/r04_bench.json was taken with another build or without fp32_b256"}
-    return {"value": rec["fp32_b256"]["value"], "unit": "frames/s", "batch_per_gpu": 256,
-            "source": "profiles/r04_bench.json fp32_b256 (N = 1, same library digest)"}
+    import glob
+    digest = lib_digest()[:12]
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench.json")), reverse=True)
+    for path in paths:
+        try:
+            with open(path) as fh:
+                rec = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        if rec.get("config", {}).get("lib_digest") == digest and "fp32_b256" in rec:
+            name = os.path.relpath(path, ROOT)
+            return {"value": rec["fp32_b256"]["value"], "unit": "frames/s", "batch_per_gpu": 256,
+                    "source": f"{name} fp32_b256 (N = 1, same library digest)"}
+    return {"value": None, "note": "no recorded N = 1 line of this build with fp32_b256 under profiles/ (rNN_bench.json)"}
 
 
 def main() -> None:
@@ -718,7 +816,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the sub-benchmarks (stft = configs[2], f16 = configs[4], fp32_b256, b1)")
-    ap.add_argument("--extras", default="stft,f16,fp32_b256,b1,exact_f32,e2e_config0",
+    ap.add_argument("--extras", default="stft,f16,fp32_b256,b1,exact_f32,e2e_config0,host_boundary",
                     help="which sub-benchmarks to run (comma list; tools/profile_bench.sh profiles with stft,f16 only, so that the "
                          "kernel statistics of the headline kernel are not mixed with other batch sizes)")
     ap.add_argument("--stft-steps", type=int, default=20)
@@ -812,6 +910,8 @@ def main() -> None:
                     out["exact_f32"] = bench_exact_f32(sd_np, dev)
                 if "e2e_config0" in extras:
                     out["e2e_config0"] = bench_e2e_config0(sd_np, dev, with_cpu=not args.no_cpu_baseline)
+                if "host_boundary" in extras:
+                    out["host_boundary"] = bench_host_boundary(sd_np, dev)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(sd_np)
         print(json.dumps(out), flush=True)
