@@ -700,7 +700,7 @@ def bench_host_boundary(sd_np, dev, batch=64, iters=8):
     (test.py:100-113), so a drop-in caller that keeps its spectrograms in host memory pays the two copies.  Three forms, batch 64 x
     513x256 fp32 (33.6 MB each way): (a) `model(x_cpu)` exactly as test.py calls it (pageable memory, wall clock), (b) pinned buffers,
     copy in -> forward -> copy out on one stream, (c) the same with the copies on their own streams, double buffered, so that batch
-    i+1 goes in and batch i-1 comes out under batch i's forward.  Plus (d) audio in host memory -> adn_stft_mag_fit -> forward ->
+    i+1 goes in and batch i-1 comes out under batch i's forward (batch i+1's copy in submitted before batch i's copy out).  Plus (d) audio in host memory -> adn_stft_mag_fit -> forward ->
     magnitudes out (configs[0]'s flow; 33.9 MB of audio per 64 clips)."""
     from audiodenoiser_amd.stft import prepare, stft_magnitude_fit
     net = make_net(sd_np, dev, "f32")
@@ -747,17 +747,31 @@ def bench_host_boundary(sd_np, dev, batch=64, iters=8):
         ev_in = [torch.cuda.Event() for _ in range(2)]
         ev_comp = [torch.cuda.Event() for _ in range(2)]
         n_it = 2 * iters
-        torch.cuda.synchronize(dev)
-        e0.record()
-        for i in range(n_it):
+        fwd_ev = []
+
+        def copy_in(i):
             k = i & 1
             with torch.cuda.stream(s_in):
                 if i >= 2:
                     s_in.wait_event(ev_comp[k])            # batch i-2's forward has read xd[k]
                 xd[k].copy_(x_pin, non_blocking=True)
                 ev_in[k].record(s_in)
+        torch.cuda.synchronize(dev)
+        copy_in(0)
+        for i in range(n_it + 2):
+            k = i & 1
+            # the next batch goes in BEFORE this batch's copy out is submitted: the copy queue is served in submission order, and a
+            # copy out that waits for its forward holds up every copy submitted behind it (tools/host_boundary_timeline.py)
+            copy_in(i + 1)
+            if i == 2:
+                e0.record()                                # behind the forward of batch 1: the pipeline is full, the clocks are up
             comp.wait_event(ev_in[k])
+            fe = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            fe[0].record()
             y = net(xd[k])
+            fe[1].record()
+            if i >= 2:
+                fwd_ev.append(fe)
             ev_comp[k].record(comp)
             with torch.cuda.stream(s_out):
                 s_out.wait_event(ev_comp[k])
@@ -765,8 +779,10 @@ def bench_host_boundary(sd_np, dev, batch=64, iters=8):
                 y.record_stream(s_out)
         comp.wait_stream(s_out)
         e1.record()
+        comp.wait_stream(s_in)
         torch.cuda.synchronize(dev)
         out["pinned_copy_streams_double_buffered"] = rate(e0.elapsed_time(e1) / n_it)
+        out["pinned_copy_streams_double_buffered"]["forward_ms_inside"] = round(sum(a.elapsed_time(b) for a, b in fwd_ev) / len(fwd_ev), 3)
         assert bool(torch.isfinite(y_pin[0]).all()) and bool(torch.isfinite(y_pin[1]).all())
 
         ad = torch.empty(a_pin.shape, device=dev)
