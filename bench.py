@@ -700,7 +700,8 @@ def bench_host_boundary(sd_np, dev, batch=64, iters=8):
     (test.py:100-113), so a drop-in caller that keeps its spectrograms in host memory pays the two copies.  Three forms, batch 64 x
     513x256 fp32 (33.6 MB each way): (a) `model(x_cpu)` exactly as test.py calls it (pageable memory, wall clock), (b) pinned buffers,
     copy in -> forward -> copy out on one stream, (c) the same with the copies on their own streams, double buffered, so that batch
-    i+1 goes in and batch i-1 comes out under batch i's forward (batch i+1's copy in submitted before batch i's copy out).  Plus (d) audio in host memory -> adn_stft_mag_fit -> forward ->
+    i+1 goes in and batch i-1 comes out under batch i's forward (batch i+1's copy in submitted before batch i's copy out).  (c') the packaged
+    form of (c), `UNet.forward_host_batches`, on pinned inputs / output views and on pageable inputs / copied outputs.  Plus (d) audio in host memory -> adn_stft_mag_fit -> forward ->
     magnitudes out (configs[0]'s flow; 33.9 MB of audio per 64 clips)."""
     from audiodenoiser_amd.stft import prepare, stft_magnitude_fit
     net = make_net(sd_np, dev, "f32")
@@ -784,6 +785,17 @@ def bench_host_boundary(sd_np, dev, batch=64, iters=8):
         out["pinned_copy_streams_double_buffered"] = rate(e0.elapsed_time(e1) / n_it)
         out["pinned_copy_streams_double_buffered"]["forward_ms_inside"] = round(sum(a.elapsed_time(b) for a, b in fwd_ev) / len(fwd_ev), 3)
         assert bool(torch.isfinite(y_pin[0]).all()) and bool(torch.isfinite(y_pin[1]).all())
+
+        # the packaged form of (c): UNet.forward_host_batches, wall clock over the whole generator (first batch's fill included)
+        for name, src, cp in (("forward_host_batches_pinned_views", x_pin, False), ("forward_host_batches_pageable_copies", x_page, True)):
+            for timed in (False, True):
+                n_b = n_it if timed else 3
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                got = sum(1 for _ in net.forward_host_batches((src for _ in range(n_b)), copy=cp))
+                el = time.perf_counter() - t0
+            assert got == n_it
+            out[name] = rate(el / n_it * 1e3)
 
         ad = torch.empty(a_pin.shape, device=dev)
         for timed in (False, True):

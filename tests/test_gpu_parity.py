@@ -147,6 +147,36 @@ def test_unet_full_size_batch256_fp32(net_invariant, dev, weights_np):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("pinned,copy", [(False, True), (True, True), (True, False)])
+def test_host_batches_pipeline_equals_plain_calls(dev, weights_np, pinned, copy):
+    """UNet.forward_host_batches (copies on their own streams, double buffered) yields, batch for batch and bit for bit, what
+    ``model(batch.cuda()).cpu()`` gives -- five batches with a short last one, pageable and pinned inputs, copied outputs and views."""
+    from audiodenoiser_amd import UNet
+    from audiodenoiser_amd.weights import make_input
+    net = UNet()
+    net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in weights_np.items()})
+    net.eval().to(dev)
+    sizes = (3, 3, 3, 3, 2)
+    batches = [torch.from_numpy(make_input(90 + i, n, 40, 48)) for i, n in enumerate(sizes)]
+    if pinned:
+        batches = [b.pin_memory() for b in batches]
+    with torch.no_grad():
+        want = [net(b.to(dev)).cpu() for b in batches]
+        got = []
+        for out in net.forward_host_batches(iter(batches), copy=copy):
+            assert not out.is_cuda and out.shape == want[len(got)].shape
+            got.append(out.clone())                     # copy=False: the view is only good until the next advance
+        assert list(net.forward_host_batches([])) == []
+        one = list(net.forward_host_batches([batches[0]]))
+        with pytest.raises(ValueError, match="larger than the first"):
+            list(net.forward_host_batches([batches[4], batches[0]]))
+        with pytest.raises(ValueError, match="every batch must be"):
+            list(net.forward_host_batches([batches[0], torch.zeros(3, 1, 40, 64)]))
+    assert len(got) == len(want) and len(one) == 1 and torch.equal(one[0], want[0])
+    for g, w in zip(got, want):
+        assert torch.equal(g, w)
+
+
 def test_reference_test_py_call_shape_cpu_model_cpu_tensors(dev, weights_np, golden_dir, tmp_path, monkeypatch):
     """Literally the reference's inference caller (test.py:63-66,100,112-114,118-122) with PYTHONPATH=compat: the
     model is loaded with map_location='cpu' and never moved, the batch is a CPU tensor, the loss inputs are CPU

@@ -398,6 +398,8 @@ def test_cpu_tensors_without_a_device_raise_instead_of_computing(weights_np):
         m(torch.zeros(1, 1, 16, 16))
     with torch.no_grad(), pytest.raises(AdnError, match="no ROCm device"):
         CombinedPerceptualLoss()(torch.zeros(1, 1, 16, 64), torch.zeros(1, 1, 16, 64))
+    with torch.no_grad(), pytest.raises(AdnError, match="no ROCm device"):
+        next(m.forward_host_batches([torch.zeros(1, 1, 16, 16)]))
 
 
 def test_perceptual_loss_frame_limit_is_reported_before_any_launch():
