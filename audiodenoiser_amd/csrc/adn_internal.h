@@ -167,7 +167,7 @@ ConvGeom conv_geom(ConvKind kind, int Cout, bool f16);
 hipError_t launch_conv_mfma(ConvKind kind, const ConvArgs &a, bool f16, hipStream_t st);
 // Winograd F(2x2,3x3) variant of the 3x3 kinds, fp32 only (wino_kernels.hip): tile 16x16 px x 32 couts, 8-ch chunks.
 hipError_t launch_wino_conv(ConvKind kind, const ConvArgs &a, hipStream_t st);
-// workgroups of one K split of a Winograd launch (what wino_ksplit() is asked about)
+// workgroups of one K split of a Winograd launch that have a tile to compute (what wino_ksplit() is asked about)
 long wino_workgroups(const ConvArgs &a);
 // Winograd F(4x4,3x3) variant (wino4_kernels.hip): tile 32x32 px x 32 couts, 8-ch chunks, weights from ConvArgs::wpk
 // in pack_wino4_3x3 layout.  wino4_applicable: plain / pooled 3x3 layers whose image the 32x32 tiles cover with little

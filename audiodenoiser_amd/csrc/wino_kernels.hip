@@ -43,6 +43,19 @@ constexpr int WT = 16;                  // output tile edge (pixels)
 constexpr int WP = WT + 2;              // halo edge
 constexpr int WKC = 8;                  // input channels per chunk
 
+// Supertile of the LDS-DMA kernel: the `sup` workgroups that run together on one XCD = gc cout tiles x gp pixel tiles (powers of
+// two, gc * gp = sup).  8 x 8 by default; a launch with fewer pixel tiles than that (one clip at the deep levels: 2 tiles at
+// 32x16) gets a flatter supertile -- fewer pixel tiles, more cout tiles -- instead of workgroups that exit at once.
+__host__ __device__ __forceinline__ void wino_supertile(int nct, long ptiles, int sup, int &gc, int &gp)
+{
+    gc = nct < 8 ? nct : 8;
+    gp = sup / gc;
+    while (gp > 1 && (gp >> 1) >= ptiles && gc * 2 <= nct) {
+        gp >>= 1;
+        gc <<= 1;
+    }
+}
+
 __device__ __forceinline__ int wino_xcd_remap(int b, int nwg)
 {
     const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
@@ -111,13 +124,14 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
     // Workgroup -> (pixel tile, cout tile).  After the XCD remap, SUP consecutive ids run together on one XCD;
     // they form a supertile of gc cout tiles x gp pixel tiles so that every U slab and every halo is fetched into
     // that XCD's L2 once and hit by the other workgroups of the supertile.  The two workgroups resident on one CU are
-    // members wl and wl+32 (tools/ubench/placement.hip: block ids 256 apart): with gc = 8 they have the same cout tile,
+    // members wl and wl+32 (tools/ubench/placement.hip: block ids 256 apart): with gc = 8 (16, 32) they have the same cout tile,
     // i.e. the same U slab (an L1 hit for the second); pairing them on the same pixel tile instead measured 1 % slower.
     const int split = SPLIT ? (int)blockIdx.x / p.nwg_base : 0;
     const int nloc = SPLIT ? p.nchunk / p.ksplit : p.nchunk;      // chunks this workgroup sums
     const int c0 = split * nloc;                                   // first of them
     int lid = SPLIT ? wino_xcd_remap((int)blockIdx.x - split * p.nwg_base, p.nwg_base) : wino_xcd_remap(blockIdx.x, gridDim.x);
-    const int gc = p.nct < 8 ? p.nct : 8, gp = G::SUP / gc;
+    int gc, gp;
+    wino_supertile(p.nct, (long)p.N * p.tilesY * p.tilesX, G::SUP, gc, gp);
     const int ncg = p.nct / gc;
     const int sg = lid / G::SUP, wl = lid - sg * G::SUP;
     const int ct = (sg % ncg) * gc + wl % gc;
@@ -523,8 +537,9 @@ hipError_t launch_wino_dma_n(ConvKind kind, const ConvArgs &a, hipStream_t st)
     ConvArgs a2 = a;
     a2.tilesX = (a.W + G::TPW - 1) / G::TPW;
     // grid padded to whole supertiles (see the kernel): gp pixel tiles x gc cout tiles, gc*gp = SUP
-    const long gc = a2.nct < 8 ? a2.nct : 8, gp = G::SUP / gc;
     const long ptiles = (long)a2.N * a2.tilesY * a2.tilesX;
+    int gc, gp;
+    wino_supertile(a2.nct, ptiles, G::SUP, gc, gp);
     const long nwg = ((ptiles + gp - 1) / gp) * gp * a2.nct;
     if (nwg <= 0 || nwg > 0x7fffffffL) return hipErrorInvalidValue;
     // the attribute is per device: remember which devices of this process have it (one process per GPU is the
@@ -611,9 +626,7 @@ long wino_workgroups(const ConvArgs &a)
 {
     using G = DmaGeom<4>;
     const long tilesX = (a.W + G::TPW - 1) / G::TPW;
-    const long gc = a.nct < 8 ? a.nct : 8, gp = G::SUP / gc;
-    const long ptiles = (long)a.N * a.tilesY * tilesX;
-    return ((ptiles + gp - 1) / gp) * gp * a.nct;
+    return (long)a.N * a.tilesY * tilesX * a.nct;       // without the padding of the last supertile: those exit at once
 }
 
 hipError_t launch_wino_conv(ConvKind kind, const ConvArgs &a, hipStream_t st)
