@@ -81,6 +81,7 @@ struct ConvTLayer {
     int Cin, Cout;
     size_t w_off, b_off;
     size_t w16_off, braw_off;   // fp16 path: pack_convt16 form of the weights (convt16_f16), 0 = none; the Cout biases as they are
+                                // (fp32 split-bf16 form: braw_off too, for the K-split reduce launch)
 };
 
 }  // namespace
@@ -93,6 +94,7 @@ struct adn_unet {
     Conv3x3Layer c3[17];                   // the 17 MFMA 3x3 convolutions in execution order
     ConvTLayer ct[4];
     size_t out_w = 0;               // Conv2d(64 -> num_classes, 1x1): [class][64]
+    size_t zero_off = 0;            // 2048 zero floats
     float out_b = 0.f;              // bias of class 0 (the fused 1x1 tails handle one class)
     std::vector<float> out_bias;    // all classes
     int in_ch = 1, n_classes = 1;   // UNet(in_channels, num_classes) (model.py:54); the reference's callers use (1, 1)
@@ -349,6 +351,14 @@ struct Plan {
     size_t tA, tB, skip[4], pool[4], part, total;   // BYTE offsets into the workspace (part: split-K partial sums)
 };
 
+// K splits of the fp32 transposed convolution Cin -> Cout on an H x W input (conv_dma's tile: 8 x 16 pixels x 128 GEMM columns,
+// 16-channel chunks); make_plan sizes the partial buffer with it, run_forward launches with it
+int convt_ks(int N, int H, int W, int Cin, int Cout)
+{
+    const long nwg = (long)N * ((H + 7) / 8) * ((W + 15) / 16) * (4 * Cout / 128);
+    return adn::convt_ksplit(nwg, Cin / 16);
+}
+
 bool make_plan(int N, int F, int T, bool f16, Plan &p)
 {
     // F*T < 2^27: ONE 8-channel block of a full-resolution fp32 image (F*T*32 bytes) stays below 4 GB, the range of a buffer
@@ -392,6 +402,10 @@ bool make_plan(int N, int F, int T, bool f16, Plan &p)
         layer(0, 64, 64);
         layer(4, 512, 1024); layer(4, 1024, 1024);
         for (int l = 3; l >= 0; --l) { layer(l, 2 * CH[l], CH[l]); layer(l, CH[l], CH[l]); }
+        for (int l = 3; l >= 0; --l) {                   // K-split transposed convolutions (level l + 1 -> l), tiles of 8 x 16 px x 128 columns
+            const int ks = convt_ks(N, p.H[l + 1], p.W[l + 1], CH[l + 1], CH[l]);
+            if (ks > 1) need = std::max(need, (size_t)ks * N * (2 * p.H[l + 1]) * (2 * p.W[l + 1]) * CH[l]);
+        }
         o += (need * 4 + 255) & ~size_t(255);
     }
     p.total = o;
@@ -647,7 +661,18 @@ int forward_impl(adn_unet *h, const float *x, float *y, int N, int F, int T, voi
                 t16 = true;
             }
         }
-        if (!t16) ADN_HIP(adn::launch_conv_mfma(adn::CONVT2X2, t, f16, st));
+        // one clip at the deep levels: the K loop cut over several workgroups + a reduce launch (fp32 split-bf16 form, automatic
+        // kernel choice only: like the 3x3 layers' split, it makes the summation order depend on the batch size)
+        const int tks = (!f16 && h->convt_split && !h->batch_invariant && g.TH == 8 && g.BN == 128 && g.KC == 16)
+                            ? convt_ks(N, uh, uw, upc, co) : 1;
+        if (tks > 1) {
+            t.ksplit = tks;
+            t.out = part;
+            t.bias = h->dev + h->zero_off;
+            ADN_HIP(adn::launch_conv_mfma(adn::CONVT2X2, t, f16, st));
+            ADN_HIP(adn::launch_convt_reduce(part, h->dev + TL.braw_off, static_cast<float *>(Y), tks, N, 2 * uh, 2 * uw, co, st));
+        } else if (!t16)
+            ADN_HIP(adn::launch_conv_mfma(adn::CONVT2X2, t, f16, st));
         // first conv of the DoubleConv reads cat([skip, x1]) virtually
         adn::ConvArgs a = conv_args(h, h->c3[li], adn::CONV3X3_RELU, ws + p.skip[l], co, Y, co, 2 * uh, 2 * uw, X, nullptr,
                                     N, p.H[l], p.W[l]);
@@ -883,6 +908,8 @@ int adn_unet_create_general(adn_unet **handle, int device, const float *const *t
         } else if (h->convt_split) {
             TL.w_off = reserve(((size_t)3 * 4 * cin * co + 1) / 2);          // three bf16 planes
             pack_convt_split(t[ti], cin, co, reinterpret_cast<uint16_t *>(host.data() + TL.w_off));
+            TL.braw_off = reserve(co);
+            std::memcpy(host.data() + TL.braw_off, t[ti + 1], sizeof(float) * co);
         } else {
             TL.w_off = reserve((size_t)4 * cin * co);
             pack_convt<float>(t[ti], cin, co, host.data() + TL.w_off);
@@ -897,6 +924,7 @@ int adn_unet_create_general(adn_unet **handle, int device, const float *const *t
         add_conv3(2 * co, co);
         add_conv3(co, co);
     }
+    h->zero_off = reserve(4 * 512);                                  // zeros: the bias of K-split transposed convolutions' slices
     h->out_w = reserve((size_t)64 * h->n_classes);                   // out.weight (K, 64, 1, 1) is already [class][64]
     std::memcpy(host.data() + h->out_w, t[ti], sizeof(float) * 64 * h->n_classes);
     h->out_bias.assign(t[ti + 1], t[ti + 1] + h->n_classes);

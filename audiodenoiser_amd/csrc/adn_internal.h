@@ -112,7 +112,8 @@ struct ConvArgs {
     int nwg_total;         // wino4_conv_f32 only: logical workgroup ids (= tiles incl. supertile padding) of the launch
     int split;             // fp32 transposed convolution only: 1 = weights are three bf16 planes (pack_convt_split), the contraction
                            // runs as six bf16 MFMA products per term pair with fp32 accumulation (conv_dma<..., SPLIT>)
-    // split-K (small batches, Winograd kernel only): `ksplit` workgroups share one output tile, each sums a slice
+    // split-K (small batches; F(2x2,3x3) kernel, and the fp32 transposed convolutions with `out` = the partial buffer -- see
+    // conv_dma's KSPLIT): `ksplit` workgroups share one output tile, each sums a slice
     // of nchunk/ksplit chunks and writes raw partial sums to `partial` [split][N][H][W][Cout]; a second launch adds
     // them in a fixed order and applies bias / ReLU / pooling.  ksplit = 1: everything in one launch.
     int ksplit;
@@ -148,6 +149,16 @@ inline int wino_ksplit(long nwg, int nchunk)
     return ks;
 }
 
+// Number of K splits for a transposed convolution (fp32 split-bf16 form) launched as `nwg` workgroups of `nchunk` 16-channel chunks:
+// one clip at the two deepest levels runs 64 / 128 workgroups through 64 / 32 chunks of ~1 us each (latency-bound: a chunk is 12 KB of
+// weights and 32 MFMAs per wave); cut until the grid has a workgroup per CU, never below 8 chunks per slice.
+inline int convt_ksplit(long nwg, int nchunk)
+{
+    int ks = 1;
+    while (ks < 8 && nwg * ks * 2 <= 256 && nchunk % (ks * 2) == 0 && nchunk / (ks * 2) >= 8) ks *= 2;
+    return ks;
+}
+
 // CONV3X3_RELU_DOT (Winograd kernel only): conv3x3 + BN + ReLU whose 64-channel result is never written; instead every
 // workgroup contracts its 32 output channels with the weights of the following 1x1 convolution (reference model.py:68,93,
 // the network's last layer) and stores one float per pixel into plane `ct` of ConvArgs::dot_out; launch_dot_finish adds
@@ -165,6 +176,9 @@ ConvGeom conv_geom(ConvKind kind, int Cout, bool f16);
 
 // Direct implicit-GEMM kernels (conv_kernels.hip), fp32 or fp16 storage.
 hipError_t launch_conv_mfma(ConvKind kind, const ConvArgs &a, bool f16, hipStream_t st);
+// second launch of a K-split transposed convolution (ConvArgs::ksplit > 1, fp32 split-bf16 form): out = sum of the copies + bias
+hipError_t launch_convt_reduce(const float *partial, const float *bias, float *out, int ksplit, int N, int Ho, int Wo, int Cout,
+                               hipStream_t st);
 // Winograd F(2x2,3x3) variant of the 3x3 kinds, fp32 only (wino_kernels.hip): tile 16x16 px x 32 couts, 8-ch chunks.
 hipError_t launch_wino_conv(ConvKind kind, const ConvArgs &a, hipStream_t st);
 // workgroups of one K split of a Winograd launch that have a tile to compute (what wino_ksplit() is asked about)

@@ -506,10 +506,14 @@ struct DmaCfg {
 // lo = NaN, so the sum is NaN where the exact-fp32 form may give +-inf (tests: test_convt_split_extreme_operands).
 typedef adn_bf16x8 bf16x8;
 
-template <typename T, int TH, int BN, int WM, int WN, int TAPS, int KG, int EPI, int WPE, int SPLIT = 0>
+// KSPLIT = 1 (transposed convolutions at small batch, ConvArgs::ksplit > 1): the grid is ksplit copies of the tile grid; copy `split`
+// sums chunks [split * nchunk / ksplit, +nchunk / ksplit) and stores raw sums (the launcher passes a zero bias) as "clip" n + split * N
+// of ConvArgs::out = the partial buffer [split][N][image]; convt_reduce_kernel adds the copies in a fixed order and the bias.
+template <typename T, int TH, int BN, int WM, int WN, int TAPS, int KG, int EPI, int WPE, int SPLIT = 0, int KSPLIT = 0>
 __global__ __launch_bounds__(64 * WM * WN, WPE) void conv_dma(const ConvArgs p)
 {
     using C = DmaCfg<T, TH, BN, WM, WN, TAPS, KG, SPLIT>;
+    static_assert(!KSPLIT || EPI == CONVT2X2, "K split: transposed convolutions only (one source)");
     static_assert(!SPLIT || (sizeof(T) == 4 && KG == 2 && TAPS == 1), "SPLIT: fp32 storage, one 16-channel chunk (two fp32 k-groups), 1 tap");
     constexpr int NT = C::NT, EPV = Elem<T>::EPV, HALO = C::HALO, PW = C::PW;
     static_assert(2 * EPV == ACT_BLOCK<T>, "one k-group = one channel block of the activation layout");   // KG blocks per chunk
@@ -529,6 +533,12 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void conv_dma(const ConvArgs p)
     const int hh = lane >> 5, l31 = lane & 31;
 
     int lid = xcd_remap(blockIdx.x, gridDim.x);
+    int ksp = 0;                                       // KSPLIT: which slice of the K loop this copy of the tile grid sums
+    if constexpr (KSPLIT) {
+        ksp = lid / p.nwg_base;
+        lid -= ksp * p.nwg_base;
+    }
+    const int nloc = KSPLIT ? p.nchunk / p.ksplit : p.nchunk;          // chunks this workgroup sums
     int ct, tx, ty, n;
     if (p.fdGc.d) {                                    // launch constants as reciprocals (FastDiv, adn_internal.h): no software divides
         const int q1 = fastdiv(lid, p.fdGc.d, p.fdGc.m);                   // fdGc = nct here
@@ -556,6 +566,10 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void conv_dma(const ConvArgs p)
                                                 (unsigned)((size_t)p.nchunk * B_DW * 4));
     unsigned cstr = (unsigned)((size_t)KG * p.s0.H * p.s0.W * ACT_BLOCK<T> * sizeof(T));
     unsigned wsoff = 0;                                 // byte offset of the next chunk's slab
+    if constexpr (KSPLIT) {
+        hptr += (size_t)(ksp * nloc) * cstr;
+        wsoff = (unsigned)(ksp * nloc) * (unsigned)(B_DW * 4);
+    }
     const unsigned loff = lane * 16;
     // one wave-instruction of a chunk's copy (slots [k*NT + 64*wave, +64) of image `buf`): halo part or weight part
     unsigned hcur[A_ROUNDS];
@@ -622,8 +636,8 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void conv_dma(const ConvArgs p)
     dma_chunk(0, 0, false);                            // halo of chunk 0 (its weight slab went out before the plan)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int c = 0; c < p.nchunk; ++c) {
-        if (c + 1 < p.nchunk) dma_chunk(c + 1, (c + 1) & 1);          // lands under the MFMAs below
+    for (int c = 0; c < nloc; ++c) {
+        if (c + 1 < nloc) dma_chunk(c + 1, (c + 1) & 1);              // lands under the MFMAs below
         const float *img = smem + (size_t)(c & 1) * SLOTS * 4;
         if constexpr (SPLIT) {
             // lane (row l31, half hh) holds channels 8 hh .. 8 hh + 7 of its pixel = k-group hh of the chunk (two 16-byte slots)
@@ -692,7 +706,7 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void conv_dma(const ConvArgs p)
         constexpr size_t tile = (size_t)TH * TW * (BN + 16 / sizeof(T)) * sizeof(T);
         constexpr int HALVES = tile <= C::LDS_BYTES ? 1 : 2;
         static_assert(tile / HALVES <= C::LDS_BYTES, "staging tile (or half of it) must fit the two images");
-        conv_epilogue_staged<T, TH, BN, WM, WN, EPI, HALVES>(p, acc, bias_r, smem, tid, lane, wave, ct, n, ty, tx);
+        conv_epilogue_staged<T, TH, BN, WM, WN, EPI, HALVES>(p, acc, bias_r, smem, tid, lane, wave, ct, KSPLIT ? n + ksp * p.N : n, ty, tx);
     } else {
         conv_epilogue<T, TH, BN, WM, WN, EPI>(p, acc, bias_r, lane, wave, ct, n, ty, tx);
     }
@@ -860,13 +874,15 @@ hipError_t launch_cfg(const ConvArgs &a, hipStream_t st)
     return hipGetLastError();
 }
 
-template <typename T, int TH, int BN, int WM, int WN, int TAPS, int KG, int EPI, int WPE, int SPLIT = 0>
+template <typename T, int TH, int BN, int WM, int WN, int TAPS, int KG, int EPI, int WPE, int SPLIT = 0, int KSPLIT = 0>
 hipError_t launch_dma_cfg(const ConvArgs &a, hipStream_t st)
 {
     using C = DmaCfg<T, TH, BN, WM, WN, TAPS, KG, SPLIT>;
     const long nwg = (long)a.N * a.tilesY * a.tilesX * a.nct;
-    if (nwg <= 0 || nwg > 0x7fffffffL) return hipErrorInvalidValue;
+    const int ks = KSPLIT ? a.ksplit : 1;
+    if (nwg <= 0 || ks < 1 || nwg * ks > 0x7fffffffL || a.nchunk % ks) return hipErrorInvalidValue;
     ConvArgs a2 = a;                                    // reciprocals of the tile decode's divisors (fdGc = nct; fdGc.d = 0: plain division)
+    a2.nwg_base = (int)nwg;
     a2.fdGc = a2.fdNcg = a2.fdTx = a2.fdTy = FastDiv{0u, 0u};
     const long maxd = a.nct > a.tilesX ? (a.nct > a.tilesY ? a.nct : a.tilesY) : (a.tilesX > a.tilesY ? a.tilesX : a.tilesY);
     if ((unsigned long long)nwg * (unsigned long long)maxd < 0x100000000ull) {
@@ -874,7 +890,7 @@ hipError_t launch_dma_cfg(const ConvArgs &a, hipStream_t st)
         a2.fdTx = make_fastdiv((unsigned)a.tilesX);
         a2.fdTy = make_fastdiv((unsigned)a.tilesY);
     }
-    auto kern = conv_dma<T, TH, BN, WM, WN, TAPS, KG, EPI, WPE, SPLIT>;
+    auto kern = conv_dma<T, TH, BN, WM, WN, TAPS, KG, EPI, WPE, SPLIT, KSPLIT>;
     if (C::LDS_BYTES > 64 * 1024) {
         // the attribute is per device: remember which devices of this process have it
         static std::atomic<unsigned long long> attr_mask{0};
@@ -888,8 +904,22 @@ hipError_t launch_dma_cfg(const ConvArgs &a, hipStream_t st)
             attr_mask.fetch_or(bit, std::memory_order_release);
         }
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(C::NT), C::LDS_BYTES, st, a2);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nwg * ks)), dim3(C::NT), C::LDS_BYTES, st, a2);
     return hipGetLastError();
+}
+
+// Second launch of a K-split transposed convolution: out = sum over the copies (fixed order) + bias; 16 bytes per thread.
+// Layout of every copy and of the output: [clip][channel block of 8][pixel][8] (C8).
+__global__ __launch_bounds__(256) void convt_reduce_kernel(const f32x4 *__restrict__ partial, const float *__restrict__ bias,
+                                                           f32x4 *__restrict__ out, int ksplit, long n4, long hw, int cblocks)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int c = (int)((i / (2 * hw)) % cblocks) * 8 + (int)(i & 1) * 4;      // two 16-byte pieces per pixel and channel block
+    f32x4 v = partial[i];
+    for (int s = 1; s < ksplit; ++s) v += partial[(size_t)s * n4 + i];
+    v += *reinterpret_cast<const f32x4 *>(bias + c);
+    out[i] = v;
 }
 
 template <typename T>
@@ -910,6 +940,8 @@ hipError_t launch_conv_mfma_t(ConvKind kind, const ConvArgs &a, hipStream_t st)
         if (kind == CONV3X3_RELU_DOT) return hipErrorInvalidValue;     // fp32: only the Winograd kernel fuses the last layer
         if (kind == CONVT2X2) {
             // a.split: weights packed as three bf16 planes (pack_convt_split): the split-bf16 form on the bf16 matrix cores
+            if (a.split && a.ksplit > 1) return launch_dma_cfg<T, 8, 128, 2, 2, 1, CONVT_KG, CONVT2X2, 3, 1, 1>(a, st);
+            if (a.ksplit > 1) return hipErrorInvalidValue;       // the K split exists for the split-bf16 form only
             if (a.split) return launch_dma_cfg<T, 8, 128, 2, 2, 1, CONVT_KG, CONVT2X2, 3, 1>(a, st);
             return launch_dma_cfg<T, 8, 128, 2, 2, 1, CONVT_KG, CONVT2X2, CONVT_WPE>(a, st);
         }
@@ -937,6 +969,17 @@ ConvGeom conv_geom(ConvKind kind, int Cout, bool f16)
 hipError_t launch_conv_mfma(ConvKind kind, const ConvArgs &a, bool f16, hipStream_t st)
 {
     return f16 ? launch_conv_mfma_t<_Float16>(kind, a, st) : launch_conv_mfma_t<float>(kind, a, st);
+}
+
+hipError_t launch_convt_reduce(const float *partial, const float *bias, float *out, int ksplit, int N, int Ho, int Wo, int Cout,
+                               hipStream_t st)
+{
+    const long n4 = (long)N * Ho * Wo * Cout / 4;
+    const long blocks = (n4 + 255) / 256;
+    if (ksplit < 2 || (Cout & 7) || blocks <= 0 || blocks > 0x7fffffffL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(convt_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<const f32x4 *>(partial), bias,
+                       reinterpret_cast<f32x4 *>(out), ksplit, n4, (long)Ho * Wo, Cout / 8);
+    return hipGetLastError();
 }
 
 hipError_t launch_conv_first(const float *x, const float *w9x64, const float *bias, void *out, bool f16,
