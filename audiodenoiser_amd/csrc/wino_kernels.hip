@@ -492,13 +492,15 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(2, 2
 }
 
 // Second launch of a split-K layer: out = ReLU(sum over splits (fixed order) + bias), plus the 2x2 max-pool.
-// One thread per (2x2 pixel block, 4 output channels).
+// Pooling form: one thread per (2x2 pixel block, 4 output channels); plain form: one thread per (pixel, 4 output channels) -- the
+// layers that are split have few pixels (one clip at 32x16 ... 128x64), the launch is latency: more threads, shorter threads.
 template <int EPI>
 __global__ __launch_bounds__(256) void wino_reduce_kernel(const float *__restrict__ partial, const float *__restrict__ bias,
                                                           float *__restrict__ out, float *__restrict__ pool, int ksplit,
                                                           int N, int H, int W, int Cout)
 {
-    const int cq = Cout / 4, bh = (H + 1) / 2, bw = (W + 1) / 2;
+    constexpr bool POOL = EPI == CONV3X3_RELU_POOL;
+    const int cq = Cout / 4, bh = POOL ? (H + 1) / 2 : H, bw = POOL ? (W + 1) / 2 : W;
     const long total = (long)N * bh * bw * cq;
     const long id = (long)blockIdx.x * 256 + threadIdx.x;
     if (id >= total) return;
@@ -509,24 +511,32 @@ __global__ __launch_bounds__(256) void wino_reduce_kernel(const float *__restric
     const int by = (int)(r % bh), n = (int)(r / bh);
     const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + c4);
     const size_t img = (size_t)H * W * Cout, split_stride = (size_t)N * img;
-    f32x4 mx = {0.f, 0.f, 0.f, 0.f};
+    auto finish = [&](int gy, int gx) {
+        const size_t o = (size_t)n * img + ((size_t)gy * W + gx) * Cout + c4;      // partial sums: pixel-major
+        f32x4 v = *reinterpret_cast<const f32x4 *>(partial + o);
+        for (int s = 1; s < ksplit; ++s) v += *reinterpret_cast<const f32x4 *>(partial + s * split_stride + o);
+        v += bv;
+        v.x = relu_nan(v.x); v.y = relu_nan(v.y); v.z = relu_nan(v.z); v.w = relu_nan(v.w);
+        *reinterpret_cast<f32x4 *>(out + (size_t)n * img + act_off<float>(Cout, (long)H * W, (long)gy * W + gx, c4)) = v;   // C8
+        return v;
+    };
+    if constexpr (!POOL) {
+        finish(by, bx);
+    } else {
+        f32x4 mx = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int gy = 2 * by + a, gx = 2 * bx + b;
-            if (gy >= H || gx >= W) continue;
-            const size_t o = (size_t)n * img + ((size_t)gy * W + gx) * Cout + c4;      // partial sums: pixel-major
-            f32x4 v = *reinterpret_cast<const f32x4 *>(partial + o);
-            for (int s = 1; s < ksplit; ++s) v += *reinterpret_cast<const f32x4 *>(partial + s * split_stride + o);
-            v += bv;
-            v.x = relu_nan(v.x); v.y = relu_nan(v.y); v.z = relu_nan(v.z); v.w = relu_nan(v.w);
-            *reinterpret_cast<f32x4 *>(out + (size_t)n * img + act_off<float>(Cout, (long)H * W, (long)gy * W + gx, c4)) = v;   // C8
-            mx.x = max_nan(mx.x, v.x); mx.y = max_nan(mx.y, v.y); mx.z = max_nan(mx.z, v.z); mx.w = max_nan(mx.w, v.w);
-        }
-    if (EPI == CONV3X3_RELU_POOL && by < H / 2 && bx < W / 2)
-        *reinterpret_cast<f32x4 *>(pool + (size_t)n * (H / 2) * (W / 2) * Cout +
-                                   act_off<float>(Cout, (long)(H / 2) * (W / 2), (long)by * (W / 2) + bx, c4)) = mx;
+            for (int b = 0; b < 2; ++b) {
+                const int gy = 2 * by + a, gx = 2 * bx + b;
+                if (gy >= H || gx >= W) continue;
+                const f32x4 v = finish(gy, gx);
+                mx.x = max_nan(mx.x, v.x); mx.y = max_nan(mx.y, v.y); mx.z = max_nan(mx.z, v.z); mx.w = max_nan(mx.w, v.w);
+            }
+        if (by < H / 2 && bx < W / 2)
+            *reinterpret_cast<f32x4 *>(pool + (size_t)n * (H / 2) * (W / 2) * Cout +
+                                       act_off<float>(Cout, (long)(H / 2) * (W / 2), (long)by * (W / 2) + bx, c4)) = mx;
+    }
 }
 
 template <int NW>
@@ -575,7 +585,9 @@ hipError_t launch_wino_dma_n(ConvKind kind, const ConvArgs &a, hipStream_t st)
                            st, a2);
         le = hipGetLastError();
         if (le != hipSuccess) return le;
-        const long items = (long)a2.N * ((a2.H + 1) / 2) * ((a2.W + 1) / 2) * (a2.Cout / 4);
+        const long items = kind == CONV3X3_RELU_POOL ? (long)a2.N * ((a2.H + 1) / 2) * ((a2.W + 1) / 2) * (a2.Cout / 4)
+                                                     : (long)a2.N * a2.H * a2.W * (a2.Cout / 4);
+        if (items > 0x7fffffffL * 256L) return hipErrorInvalidValue;
         const unsigned blocks = (unsigned)((items + 255) / 256);
         if (kind == CONV3X3_RELU_POOL)
             hipLaunchKernelGGL(wino_reduce_kernel<CONV3X3_RELU_POOL>, dim3(blocks), dim3(256), 0, st, a2.partial, a2.bias,
