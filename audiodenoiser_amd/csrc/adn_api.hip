@@ -407,6 +407,18 @@ bool make_plan(int N, int F, int T, bool f16, Plan &p)
             if (ks > 1) need = std::max(need, (size_t)ks * N * (2 * p.H[l + 1]) * (2 * p.W[l + 1]) * CH[l]);
         }
         o += (need * 4 + 255) & ~size_t(255);
+    } else {
+        // fp16: K-split slices of the deep 3x3 layers at small batch (conv16_ksplit; tiles of 32 x 16 pixels x 64 couts, 16-channel chunks)
+        size_t need = 0;
+        auto layer = [&](int l, int cin, int cout) {
+            const size_t outf = (size_t)N * p.H[l] * p.W[l] * cout;
+            const int ks = adn::conv16_ksplit((long)N * ((p.H[l] + 31) / 32) * ((p.W[l] + 15) / 16) * (cout / 64), cin / 16, outf);
+            if (ks > 1) need = std::max(need, (size_t)ks * outf);
+        };
+        for (int l = 1; l < 4; ++l) { layer(l, CH[l - 1], CH[l]); layer(l, CH[l], CH[l]); }
+        layer(4, 512, 1024); layer(4, 1024, 1024);
+        for (int l = 3; l >= 0; --l) { layer(l, 2 * CH[l], CH[l]); layer(l, CH[l], CH[l]); }
+        o += (need * 4 + 255) & ~size_t(255);
     }
     p.total = o;
     return true;
@@ -507,6 +519,21 @@ hipError_t launch_conv3(const adn_unet *h, adn::ConvKind kind, const adn::ConvAr
         if (a.firstw) {                                  // fused first layer: the 64 input channels are computed inside the kernel
             a16.nchunk0 = a16.nchunk = 2;
             return adn::launch_conv16(kind, a16, true, st);
+        }
+        // one clip at the deep levels: 16-64 workgroups of a long K loop on 256 CUs -- the loop is cut over up to 8 workgroups
+        // (conv_dma<_Float16> slices, fp32 sums) and a reduce launch finishes the layer.  Automatic kernel choice only: like the
+        // fp32 path's split it makes the summation order depend on the batch size (adn_unet_set_batch_invariant pins one form)
+        if (!h->batch_invariant && partial && kind != adn::CONV3X3_RELU_DOT && h->f16_conv != 0) {
+            const int ks = adn::conv16_ksplit((long)a.N * a.tilesY * a.tilesX * a.nct, a.nchunk, (size_t)a.N * a.H * a.W * a.Cout);
+            if (ks > 1) {
+                adn::ConvArgs sl = a;
+                sl.ksplit = ks;
+                sl.out = partial;
+                sl.pool = nullptr;
+                hipError_t e = adn::launch_conv_mfma(adn::CONV3X3_RELU, sl, true, st);
+                if (e != hipSuccess) return e;
+                return adn::launch_conv_reduce_f16(kind, partial, a.bias, a.out, a.pool, ks, a.N, a.H, a.W, a.Cout, st);
+            }
         }
         if (f16_use_conv16(h, kind, a16)) return adn::launch_conv16(kind, a16, a.s0.C + a.s1.C == 64 && a.Cout == 64, st);
     }

@@ -140,6 +140,10 @@ inline bool wino4_pair_mode(const ConvArgs &a)
     return (i0 > i1 ? i0 : i1) + (size_t)a.H * a.W * 32 < (size_t)0xfffffff0u;
 }
 
+// Largest number of K splits any launcher asks for (wino_ksplit, convt_ksplit, conv16_ksplit); the reduce kernels read all the
+// copies of an element before adding them (one memory latency per element instead of one per copy)
+constexpr int ADN_MAX_KSPLIT = 8;
+
 // Number of K splits for a 3x3 layer launched as `nwg` Winograd workgroups of `nchunk` chunks: only when the grid
 // cannot fill the 512 workgroup slots of the chip (2 per CU) and the K loop is long enough to be worth cutting.
 inline int wino_ksplit(long nwg, int nchunk)
@@ -156,6 +160,19 @@ inline int convt_ksplit(long nwg, int nchunk)
 {
     int ks = 1;
     while (ks < 8 && nwg * ks * 2 <= 256 && nchunk % (ks * 2) == 0 && nchunk / (ks * 2) >= 8) ks *= 2;
+    return ks;
+}
+
+// Number of K splits for an fp16 3x3 layer launched as `nwg` workgroups (32x16 pixels x 64 couts) of `nchunk` 16-channel chunks:
+// one clip at the deep levels is 16-64 workgroups running 16-64 chunks of ~1.3 us each on a chip of 256 CUs.  Cut while the grid stays
+// within a workgroup per CU, a slice keeps >= 4 chunks and the partial sums (ksplit * out_floats fp32) stay small (32 MB).
+inline int conv16_ksplit(long nwg, int nchunk, size_t out_floats)
+{
+    if (nwg > 64) return 1;
+    int ks = 1;
+    while (ks < 8 && nwg * ks * 2 <= 256 && nchunk % (ks * 2) == 0 && nchunk / (ks * 2) >= 4 &&
+           (size_t)(ks * 2) * out_floats * 4 <= ((size_t)32 << 20))
+        ks *= 2;
     return ks;
 }
 
@@ -176,6 +193,9 @@ ConvGeom conv_geom(ConvKind kind, int Cout, bool f16);
 
 // Direct implicit-GEMM kernels (conv_kernels.hip), fp32 or fp16 storage.
 hipError_t launch_conv_mfma(ConvKind kind, const ConvArgs &a, bool f16, hipStream_t st);
+// second launch of a K-split fp16 3x3 layer (launch_conv_mfma with ConvArgs::ksplit > 1 wrote fp32 sums [split][N][H][W][Cout])
+hipError_t launch_conv_reduce_f16(ConvKind kind, const float *partial, const float *bias, void *out, void *pool, int ksplit, int N,
+                                  int H, int W, int Cout, hipStream_t st);
 // second launch of a K-split transposed convolution (ConvArgs::ksplit > 1, fp32 split-bf16 form): out = sum of the copies + bias
 hipError_t launch_convt_reduce(const float *partial, const float *bias, float *out, int ksplit, int N, int Ho, int Wo, int Cout,
                                hipStream_t st);

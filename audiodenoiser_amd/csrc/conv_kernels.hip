@@ -72,6 +72,32 @@ __host__ __device__ __forceinline__ void convt_column(int col, int Cout, int &ij
     co = 64 * cg + c64;
 }
 
+// Epilogue of a K-split slice (3x3 layers): the fp32 sums as they are, pixel-major [clip][H][W][Cout] (a lane's 32 neighbours hold
+// 32 consecutive columns of one pixel: 128-byte runs).  Accumulator layout: see conv_epilogue.
+template <int TH, int BN, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue_raw(const ConvArgs &p, f32x16 (&acc)[TH * TW / 32 / WM][BN / 32 / WN], int lane, int wave,
+                                                  int ct, int n, int ty, int tx)
+{
+    constexpr int MB = TH * TW / 32 / WM, NB = BN / 32 / WN;
+    const int wm = wave / WN, wn = wave % WN;
+    const int hh = lane >> 5, l31 = lane & 31;
+    float *ob = static_cast<float *>(p.out) + (size_t)n * p.H * p.W * p.Cout;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int col = ct * BN + (wn * NB + j) * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            const int trow0 = (wm * MB + i) * 2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const int gy = ty * TH + trow0 + (m >> 4), gx = tx * TW + (m & 15);
+                if (gy < p.H && gx < p.W) ob[((size_t)gy * p.W + gx) * p.Cout + col] = acc[i][j][r];
+            }
+        }
+    }
+}
+
 // Epilogue shared by the register-staged and the LDS-DMA kernels: folded-BN bias (+ ReLU, + 2x2 max-pool) or the
 // pixel-shuffle store of the transposed convolution.
 template <typename T, int TH, int BN, int WM, int WN, int EPI>
@@ -506,14 +532,16 @@ struct DmaCfg {
 // lo = NaN, so the sum is NaN where the exact-fp32 form may give +-inf (tests: test_convt_split_extreme_operands).
 typedef adn_bf16x8 bf16x8;
 
-// KSPLIT = 1 (transposed convolutions at small batch, ConvArgs::ksplit > 1): the grid is ksplit copies of the tile grid; copy `split`
-// sums chunks [split * nchunk / ksplit, +nchunk / ksplit) and stores raw sums (the launcher passes a zero bias) as "clip" n + split * N
-// of ConvArgs::out = the partial buffer [split][N][image]; convt_reduce_kernel adds the copies in a fixed order and the bias.
+// KSPLIT = 1 (small batches, ConvArgs::ksplit > 1): the grid is ksplit copies of the tile grid; copy `split` sums chunks
+// [split * nchunk / ksplit, +nchunk / ksplit) and stores raw sums as "clip" n + split * N of ConvArgs::out = the partial buffer
+// [split][N][image].  Transposed convolutions (fp32 split-bf16 form): the usual epilogue with a zero bias from the launcher,
+// convt_reduce_kernel adds the copies in a fixed order and the bias.  fp16 3x3 layers: fp32 sums, pixel-major (conv_epilogue_raw);
+// conv_reduce_f16_kernel adds them and applies bias / ReLU / pooling.
 template <typename T, int TH, int BN, int WM, int WN, int TAPS, int KG, int EPI, int WPE, int SPLIT = 0, int KSPLIT = 0>
 __global__ __launch_bounds__(64 * WM * WN, WPE) void conv_dma(const ConvArgs p)
 {
     using C = DmaCfg<T, TH, BN, WM, WN, TAPS, KG, SPLIT>;
-    static_assert(!KSPLIT || EPI == CONVT2X2, "K split: transposed convolutions only (one source)");
+    static_assert(!KSPLIT || EPI == CONVT2X2 || (sizeof(T) == 2 && EPI == CONV3X3_RELU), "K split: transposed convolutions, fp16 3x3 layers");
     static_assert(!SPLIT || (sizeof(T) == 4 && KG == 2 && TAPS == 1), "SPLIT: fp32 storage, one 16-channel chunk (two fp32 k-groups), 1 tap");
     constexpr int NT = C::NT, EPV = Elem<T>::EPV, HALO = C::HALO, PW = C::PW;
     static_assert(2 * EPV == ACT_BLOCK<T>, "one k-group = one channel block of the activation layout");   // KG blocks per chunk
@@ -566,9 +594,17 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void conv_dma(const ConvArgs p)
                                                 (unsigned)((size_t)p.nchunk * B_DW * 4));
     unsigned cstr = (unsigned)((size_t)KG * p.s0.H * p.s0.W * ACT_BLOCK<T> * sizeof(T));
     unsigned wsoff = 0;                                 // byte offset of the next chunk's slab
+    const int c0 = KSPLIT ? ksp * nloc : 0;            // first chunk of this workgroup's slice
+    bool in2 = false;                                   // the slice starts inside the second source (virtual concat)
     if constexpr (KSPLIT) {
-        hptr += (size_t)(ksp * nloc) * cstr;
-        wsoff = (unsigned)(ksp * nloc) * (unsigned)(B_DW * 4);
+        wsoff = (unsigned)c0 * (unsigned)(B_DW * 4);
+        if (c0 > p.nchunk0) {
+            in2 = true;
+            cstr = (unsigned)((size_t)KG * p.s1.H * p.s1.W * ACT_BLOCK<T> * sizeof(T));
+            hptr = src_base(p.s1) + (size_t)(c0 - p.nchunk0) * cstr;
+        } else {
+            hptr += (size_t)c0 * cstr;                  // (c0 == nchunk0: dma_chunk switches to the second source itself)
+        }
     }
     const unsigned loff = lane * 16;
     // one wave-instruction of a chunk's copy (slots [k*NT + 64*wave, +64) of image `buf`): halo part or weight part
@@ -602,9 +638,10 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void conv_dma(const ConvArgs p)
                           ? (unsigned)act_off<T>(src.C, (long)src.H * src.W, y0 * src.W + x0, q * EPV) * (unsigned)sizeof(T) : ADN_DMA_OOB;
         }
     };
-    plan(p.s0);
+    if (in2) plan(p.s1);
+    else plan(p.s0);
 
-    // copy of chunk `c` into image `buf`: NPIECE wave-instructions per thread
+    // copy of chunk `c` (absolute index) into image `buf`: NPIECE wave-instructions per thread
     auto dma_chunk = [&](int c, int buf, bool with_b = true) {
         if (c == p.nchunk0) {                          // wave-uniform: switch to the second source (virtual concat)
             hptr = src_base(p.s1);
@@ -633,12 +670,12 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void conv_dma(const ConvArgs p)
     const int a_lane = ((wm * MB * 2 + ((lane >> 4) & 1)) * RSLOT + (lane & 15) * PSLOT) * 4 + hh * 4;
     const int b_lane = A_SLOTS * 4 + hh * BN * 4 + (wn * NB * 32 + l31) * 4;
 
-    dma_chunk(0, 0, false);                            // halo of chunk 0 (its weight slab went out before the plan)
+    dma_chunk(c0, 0, false);                           // halo of the first chunk (its weight slab went out before the plan)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int c = 0; c < nloc; ++c) {
-        if (c + 1 < nloc) dma_chunk(c + 1, (c + 1) & 1);              // lands under the MFMAs below
-        const float *img = smem + (size_t)(c & 1) * SLOTS * 4;
+    for (int c = c0; c < c0 + nloc; ++c) {
+        if (c + 1 < c0 + nloc) dma_chunk(c + 1, (c + 1 - c0) & 1);    // lands under the MFMAs below
+        const float *img = smem + (size_t)((c - c0) & 1) * SLOTS * 4;
         if constexpr (SPLIT) {
             // lane (row l31, half hh) holds channels 8 hh .. 8 hh + 7 of its pixel = k-group hh of the chunk (two 16-byte slots)
             bf16x8 ah[MB], am[MB], al[MB];
@@ -702,7 +739,9 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void conv_dma(const ConvArgs p)
     }
     // fp16: LDS-staged 16-byte stores (2-byte stores per lane otherwise).  fp32 transposed convolutions (C8 layout): staged
     // too -- a lane's direct stores would be 4 bytes into 32-byte segments, the staged form writes 1 KB runs.
-    if constexpr (sizeof(T) == 2 || EPI == CONVT2X2) {
+    if constexpr (KSPLIT && EPI != CONVT2X2) {
+        conv_epilogue_raw<TH, BN, WM, WN>(p, acc, lane, wave, ct, n + ksp * p.N, ty, tx);
+    } else if constexpr (sizeof(T) == 2 || EPI == CONVT2X2) {
         constexpr size_t tile = (size_t)TH * TW * (BN + 16 / sizeof(T)) * sizeof(T);
         constexpr int HALVES = tile <= C::LDS_BYTES ? 1 : 2;
         static_assert(tile / HALVES <= C::LDS_BYTES, "staging tile (or half of it) must fit the two images");
@@ -916,16 +955,80 @@ __global__ __launch_bounds__(256) void convt_reduce_kernel(const f32x4 *__restri
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
     const int c = (int)((i / (2 * hw)) % cblocks) * 8 + (int)(i & 1) * 4;      // two 16-byte pieces per pixel and channel block
-    f32x4 v = partial[i];
-    for (int s = 1; s < ksplit; ++s) v += partial[(size_t)s * n4 + i];
+    f32x4 t[ADN_MAX_KSPLIT];                                 // all copies in flight, then added in split order
+#pragma unroll
+    for (int s = 0; s < ADN_MAX_KSPLIT; ++s)
+        if (s < ksplit) t[s] = partial[(size_t)s * n4 + i];
+    f32x4 v = t[0];
+#pragma unroll
+    for (int s = 1; s < ADN_MAX_KSPLIT; ++s)
+        if (s < ksplit) v += t[s];
     v += *reinterpret_cast<const f32x4 *>(bias + c);
     out[i] = v;
+}
+
+// Second launch of a K-split fp16 3x3 layer: out = ReLU(sum over the copies (fixed order) + bias) as fp16 in the blocked activation
+// layout, plus the 2x2 max-pool.  Pooling form: one thread per (2x2 pixel block, 4 channels); plain form: per (pixel, 4 channels).
+typedef _Float16 f16x4r __attribute__((ext_vector_type(4)));
+template <bool POOL>
+__global__ __launch_bounds__(256) void conv_reduce_f16_kernel(const float *__restrict__ partial, const float *__restrict__ bias,
+                                                              _Float16 *__restrict__ out, _Float16 *__restrict__ pool, int ksplit,
+                                                              int N, int H, int W, int Cout)
+{
+    const int cq = Cout / 4, bh = POOL ? (H + 1) / 2 : H, bw = POOL ? (W + 1) / 2 : W;
+    const long total = (long)N * bh * bw * cq;
+    const long id = (long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= total) return;
+    const int c4 = (int)(id % cq) * 4;
+    long r = id / cq;
+    const int bx = (int)(r % bw);
+    r /= bw;
+    const int by = (int)(r % bh), n = (int)(r / bh);
+    const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + c4);
+    const size_t img = (size_t)H * W * Cout, split_stride = (size_t)N * img;
+    auto half4 = [](const f32x4 &v) { return f16x4r{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w}; };
+    auto finish = [&](int gy, int gx) {
+        const size_t o = (size_t)n * img + ((size_t)gy * W + gx) * Cout + c4;
+        f32x4 t[ADN_MAX_KSPLIT];                             // all copies in flight, then added in split order
+#pragma unroll
+        for (int s = 0; s < ADN_MAX_KSPLIT; ++s)
+            if (s < ksplit) t[s] = *reinterpret_cast<const f32x4 *>(partial + s * split_stride + o);
+        f32x4 v = t[0];
+#pragma unroll
+        for (int s = 1; s < ADN_MAX_KSPLIT; ++s)
+            if (s < ksplit) v += t[s];
+        v += bv;
+        v.x = relu_nan(v.x); v.y = relu_nan(v.y); v.z = relu_nan(v.z); v.w = relu_nan(v.w);
+        *reinterpret_cast<f16x4r *>(out + (size_t)n * img + act_off<_Float16>(Cout, (long)H * W, (long)gy * W + gx, c4)) = half4(v);
+        return v;
+    };
+    if constexpr (!POOL) {
+        finish(by, bx);
+    } else {
+        f32x4 mx = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int gy = 2 * by + a, gx = 2 * bx + b;
+                if (gy >= H || gx >= W) continue;
+                const f32x4 v = finish(gy, gx);
+                mx.x = max_nan(mx.x, v.x); mx.y = max_nan(mx.y, v.y); mx.z = max_nan(mx.z, v.z); mx.w = max_nan(mx.w, v.w);
+            }
+        if (by < H / 2 && bx < W / 2)
+            *reinterpret_cast<f16x4r *>(pool + (size_t)n * (H / 2) * (W / 2) * Cout +
+                                        act_off<_Float16>(Cout, (long)(H / 2) * (W / 2), (long)by * (W / 2) + bx, c4)) = half4(mx);
+    }
 }
 
 template <typename T>
 hipError_t launch_conv_mfma_t(ConvKind kind, const ConvArgs &a, hipStream_t st)
 {
     if constexpr (sizeof(T) == 2) {
+        if (a.ksplit > 1) {                              // a slice launch: raw fp32 sums into a.out, whatever the layer's epilogue
+            if (kind != CONV3X3_RELU) return hipErrorInvalidValue;
+            return launch_dma_cfg<T, 32, 64, 8, 1, 9, 1, CONV3X3_RELU, 4, 0, 1>(a, st);
+        }
         // fp16: the matrix cores are 16x faster than for fp32 while the CU's ingest path is not, so the kernel is
         // bound by the bytes staged per FLOP: LDS-DMA staging, and 8-wave workgroups on 32x16-pixel tiles x 64 couts
         // (132 staged bytes per MFMA; 16x16 px x 128 couts would be 164), two workgroups per CU.
@@ -971,12 +1074,29 @@ hipError_t launch_conv_mfma(ConvKind kind, const ConvArgs &a, bool f16, hipStrea
     return f16 ? launch_conv_mfma_t<_Float16>(kind, a, st) : launch_conv_mfma_t<float>(kind, a, st);
 }
 
+hipError_t launch_conv_reduce_f16(ConvKind kind, const float *partial, const float *bias, void *out, void *pool, int ksplit, int N,
+                                  int H, int W, int Cout, hipStream_t st)
+{
+    const bool pl = kind == CONV3X3_RELU_POOL;
+    const long items = pl ? (long)N * ((H + 1) / 2) * ((W + 1) / 2) * (Cout / 4) : (long)N * H * W * (Cout / 4);
+    const long blocks = (items + 255) / 256;
+    if (ksplit < 2 || ksplit > ADN_MAX_KSPLIT || (Cout & 15) || (kind != CONV3X3_RELU && !pl) || (pl && !pool) || blocks <= 0 || blocks > 0x7fffffffL)
+        return hipErrorInvalidValue;
+    if (pl)
+        hipLaunchKernelGGL(conv_reduce_f16_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, partial, bias,
+                           static_cast<_Float16 *>(out), static_cast<_Float16 *>(pool), ksplit, N, H, W, Cout);
+    else
+        hipLaunchKernelGGL(conv_reduce_f16_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, partial, bias,
+                           static_cast<_Float16 *>(out), static_cast<_Float16 *>(nullptr), ksplit, N, H, W, Cout);
+    return hipGetLastError();
+}
+
 hipError_t launch_convt_reduce(const float *partial, const float *bias, float *out, int ksplit, int N, int Ho, int Wo, int Cout,
                                hipStream_t st)
 {
     const long n4 = (long)N * Ho * Wo * Cout / 4;
     const long blocks = (n4 + 255) / 256;
-    if (ksplit < 2 || (Cout & 7) || blocks <= 0 || blocks > 0x7fffffffL) return hipErrorInvalidValue;
+    if (ksplit < 2 || ksplit > ADN_MAX_KSPLIT || (Cout & 7) || blocks <= 0 || blocks > 0x7fffffffL) return hipErrorInvalidValue;
     hipLaunchKernelGGL(convt_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<const f32x4 *>(partial), bias,
                        reinterpret_cast<f32x4 *>(out), ksplit, n4, (long)Ho * Wo, Cout / 8);
     return hipGetLastError();

@@ -513,8 +513,14 @@ __global__ __launch_bounds__(256) void wino_reduce_kernel(const float *__restric
     const size_t img = (size_t)H * W * Cout, split_stride = (size_t)N * img;
     auto finish = [&](int gy, int gx) {
         const size_t o = (size_t)n * img + ((size_t)gy * W + gx) * Cout + c4;      // partial sums: pixel-major
-        f32x4 v = *reinterpret_cast<const f32x4 *>(partial + o);
-        for (int s = 1; s < ksplit; ++s) v += *reinterpret_cast<const f32x4 *>(partial + s * split_stride + o);
+        f32x4 t[ADN_MAX_KSPLIT];                             // all copies in flight, then added in split order
+#pragma unroll
+        for (int s = 0; s < ADN_MAX_KSPLIT; ++s)
+            if (s < ksplit) t[s] = *reinterpret_cast<const f32x4 *>(partial + s * split_stride + o);
+        f32x4 v = t[0];
+#pragma unroll
+        for (int s = 1; s < ADN_MAX_KSPLIT; ++s)
+            if (s < ksplit) v += t[s];
         v += bv;
         v.x = relu_nan(v.x); v.y = relu_nan(v.y); v.z = relu_nan(v.z); v.w = relu_nan(v.w);
         *reinterpret_cast<f32x4 *>(out + (size_t)n * img + act_off<float>(Cout, (long)H * W, (long)gy * W + gx, c4)) = v;   // C8
@@ -579,7 +585,7 @@ hipError_t launch_wino_dma_n(ConvKind kind, const ConvArgs &a, hipStream_t st)
     if (a2.ksplit > 1 && kind == CONV3X3_RELU_DOT) return hipErrorInvalidValue;      // the fused layer is never split
     if (a2.ksplit > 1) {
         // split-K: raw partial sums first (the epilogue variant does not matter), then sum + bias + ReLU (+ pool)
-        if (!a2.partial || a2.nchunk % a2.ksplit || (a2.Cout & 3)) return hipErrorInvalidValue;
+        if (!a2.partial || a2.nchunk % a2.ksplit || (a2.Cout & 3) || a2.ksplit > ADN_MAX_KSPLIT) return hipErrorInvalidValue;
         a2.nwg_base = (int)nwg;
         hipLaunchKernelGGL((wino_conv_dma_f32<CONV3X3_RELU, NW, 1>), dim3((unsigned)(nwg * a2.ksplit)), dim3(64 * NW), lds,
                            st, a2);

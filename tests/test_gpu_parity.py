@@ -764,11 +764,18 @@ def test_fp16_path_batch256(dev, weights_np):
     with torch.no_grad():
         y = m(x)
         assert torch.isfinite(y).all()
-        assert torch.equal(m(x[100:101].clone())[0], y[100])
+        # default handle: a clip alone runs its deep layers as K-split slices (another summation order): close, not bit-equal
+        alone = m(x[100:101].clone())
+        assert _rel(alone.cpu().numpy(), y[100:101].cpu().numpy()) <= 5e-3
+        m.set_batch_invariant(True)                          # one kernel per layer whatever the batch: bit-equal
+        yi = m(x)
+        assert torch.equal(m(x[100:101].clone())[0], yi[100])
+        m.set_batch_invariant(False)
     sd = unet_torch.to_torch_state(weights_np)
     for i in (0, 255):
         ref = unet_torch.unet_forward(sd, x[i:i + 1].cpu()).numpy()
         assert _rel(y[i:i + 1].cpu().numpy(), ref) <= 1e-2, i
+    assert _rel(alone.cpu().numpy(), unet_torch.unet_forward(sd, x[100:101].cpu()).numpy()) <= 1e-2
     m._workspace = None
     torch.cuda.empty_cache()
 
