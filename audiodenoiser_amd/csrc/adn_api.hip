@@ -395,7 +395,11 @@ bool make_plan(int N, int F, int T, bool f16, Plan &p)
             a.N = N; a.H = p.H[l]; a.W = p.W[l];
             a.tilesY = (p.H[l] + 15) / 16;
             a.nct = cout / 32;
-            const int ks = adn::wino_ksplit(adn::wino_workgroups(a), cin / 8);
+            int ks = adn::wino_ksplit(adn::wino_workgroups(a), cin / 8);
+            // F(4x4,3x3) slices (choose_algo): 32x32-pixel tiles, two clips per tile for images at most 16 pixels wide (an upper
+            // bound of the split where pair mode is not granted)
+            const int pr = p.W[l] <= 16 ? 1 : 0;
+            ks = std::max(ks, adn::wino4_ksplit((long)((N + pr) >> pr) * ((p.H[l] + 31) / 32) * ((p.W[l] + 31) / 32) * (cout / 32), cin / 8));
             if (ks > 1) need = std::max(need, (size_t)ks * N * p.H[l] * p.W[l] * cout);
         };
         for (int l = 1; l < 4; ++l) { layer(l, CH[l - 1], CH[l]); layer(l, CH[l], CH[l]); }
@@ -498,6 +502,25 @@ Algo choose_algo(const adn_unet *h, adn::ConvKind kind, const adn::ConvArgs &a)
     }
     // F(2x2,3x3); small grids are cut along K where even its finer grid cannot fill the chip
     if (automatic && can_split) r.ksplit = adn::wino_ksplit(adn::wino_workgroups(a), a.nchunk);
+    // ... or F(4x4,3x3) cut along K (4.5 instead of 8 matrix FLOP per pixel, but 32x32-pixel tiles: a quarter of the workgroups).
+    // Decided by the per-launch times measured on one-clip and mid-size forwards (profiles/r05_b1_timelines.txt,
+    // r04_small_grid_probe.txt), in microseconds: F(4x4) 12 + 2.79 per chunk and round of 256 workgroups, F(2x2) 8 + 2.06 per chunk
+    // and round of 512; a reduce launch 4 + (copies + 1) x output bytes at 8 TB/s.
+    if (automatic && can_split && f4_ok) {
+        const long g4 = wino4_grid(a);
+        const int ks4 = adn::wino4_ksplit(g4, a.nchunk);
+        if (ks4 > 1) {
+            const long g2 = adn::wino_workgroups(a);
+            const double out_mb = (double)a.N * a.H * a.W * a.Cout * 4.0 * 1e-6;
+            auto reduce_us = [&](int ks) { return ks > 1 ? 4.0 + (ks + 1) * out_mb / 8.0 : 0.0; };
+            const double t4 = 12.0 + 2.79 * (a.nchunk / ks4) * (double)((g4 * ks4 + 255) / 256) + reduce_us(ks4);
+            const double t2 = 8.0 + 2.06 * (a.nchunk / r.ksplit) * (double)((g2 * r.ksplit + 511) / 512) + reduce_us(r.ksplit);
+            if (t4 < t2) {
+                r.f4 = true;
+                r.ksplit = ks4;
+            }
+        }
+    }
     return r;
 }
 

@@ -153,6 +153,15 @@ inline int wino_ksplit(long nwg, int nchunk)
     return ks;
 }
 
+// Number of K splits for a 3x3 layer launched as `grid` F(4x4,3x3) workgroups (one per CU) of `nchunk` chunks: while the cut grid
+// stays within a workgroup per CU and a slice keeps >= 8 chunks (the kernel's 20 000 clocks around the K loop want amortising).
+inline int wino4_ksplit(long grid, int nchunk)
+{
+    int ks = 1;
+    while (ks < ADN_MAX_KSPLIT && grid * ks * 2 <= 256 && nchunk % (ks * 2) == 0 && nchunk / (ks * 2) >= 8) ks *= 2;
+    return ks;
+}
+
 // Number of K splits for a transposed convolution (fp32 split-bf16 form) launched as `nwg` workgroups of `nchunk` 16-channel chunks:
 // one clip at the two deepest levels runs 64 / 128 workgroups through 64 / 32 chunks of ~1 us each (latency-bound: a chunk is 12 KB of
 // weights and 32 MFMAs per wave); cut until the grid has a workgroup per CU, never below 8 chunks per slice.
@@ -201,6 +210,8 @@ hipError_t launch_convt_reduce(const float *partial, const float *bias, float *o
                                hipStream_t st);
 // Winograd F(2x2,3x3) variant of the 3x3 kinds, fp32 only (wino_kernels.hip): tile 16x16 px x 32 couts, 8-ch chunks.
 hipError_t launch_wino_conv(ConvKind kind, const ConvArgs &a, hipStream_t st);
+// second launch of a split-K 3x3 layer of either Winograd kernel (wino_kernels.hip): ConvArgs::partial -> out (+ pool)
+hipError_t launch_wino_reduce(ConvKind kind, const ConvArgs &a, hipStream_t st);
 // workgroups of one K split of a Winograd launch that have a tile to compute (what wino_ksplit() is asked about)
 long wino_workgroups(const ConvArgs &a);
 // Winograd F(4x4,3x3) variant (wino4_kernels.hip): tile 32x32 px x 32 couts, 8-ch chunks, weights from ConvArgs::wpk

@@ -154,9 +154,15 @@ __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi
 constexpr int w4_piece_at(int g) { return g >= 4 ? g - 4 : -1; }     // piece (0..4) that follows MFMA group g (0..8) of a pass, -1 = none
 static_assert(W4_PATCH_READS * 9 >= 30, "the second pass must issue all 30 patch reads");
 
-template <int EPI>
+// KSPLIT = 1 (small grids, ConvArgs::ksplit > 1; plain variant only): the grid is ksplit copies of the tile grid; copy `ksp` sums
+// chunks [ksp * nchunk / ksplit, +nchunk / ksplit) and stores raw sums -- no bias, no ReLU -- pixel-major into ConvArgs::partial
+// [split][N][H][W][Cout]; wino_reduce_kernel (launch_wino_reduce) adds the copies in a fixed order and finishes the layer.
+#define W4_NCHUNK (KSPLIT ? nloc : p.nchunk)             /* chunks this workgroup sums */
+#define W4_NCHUNK0 (KSPLIT ? nchunk0l : p.nchunk0)       /* (local) index of the first chunk of the second source */
+template <int EPI, int KSPLIT = 0>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino4_conv_f32(const ConvArgs p)
 {
+    static_assert(!KSPLIT || EPI == CONV3X3_RELU, "K split: the plain variant stores the raw sums");
     extern __shared__ __attribute__((aligned(16))) float smem[];   // the ONLY LDS object (two images)
     // Two source forms of the same arithmetic, chosen per epilogue by measurement (hipcc's register allocation of the K loop
     // is sensitive to what has to survive it): LEAN keeps nothing thread-id-derived alive across the loop (no scratch
@@ -180,7 +186,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // workgroup -> (pixel tile, cout tile): SUP consecutive ids (after the XCD remap) run together on one XCD and form
     // a supertile of gc cout tiles x gp pixel tiles, so every U slab and every halo is an L2 hit for all but one of them
     // (gc = as many cout tiles as there are, up to all 32 slots: measured 0.5 % faster than capping gc at 8)
-    const int lid = xcd_remap4(blockIdx.x, gridDim.x);
+    int lid = xcd_remap4(blockIdx.x, gridDim.x);
+    int ksp = 0;                                          // KSPLIT: which slice of the K loop this copy of the tile grid sums
+    if constexpr (KSPLIT) {
+        ksp = lid / p.nwg_base;
+        lid -= ksp * p.nwg_base;
+    }
+    const int nloc = KSPLIT ? p.nchunk / p.ksplit : 0, c0 = ksp * nloc, nchunk0l = p.nchunk0 - c0;
+    (void)nloc; (void)c0; (void)nchunk0l;
     const int pair = p.pair;                              // 1: two clips side by side in the tile (see RSL above)
     int ct, pt, tx, ty, n;
     if (p.fdGc.d) {
@@ -215,7 +228,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         const_cast<float *>(static_cast<const float *>(p.wpk)) + (size_t)ct * p.nchunk * (USLOTS * 4), 0,
         p.nchunk * (USLOTS * 16), 0x00020000);             // the U slabs of this cout tile, chunk after chunk
     const unsigned uoff = tid * 16;                        // this lane's 16 bytes inside a 512-slot round
-    unsigned usoff = 0;                                    // byte offset of the next chunk's slab
+    unsigned usoff = KSPLIT ? (unsigned)c0 * (unsigned)(USLOTS * 16) : 0u;   // byte offset of the next chunk's slab
 #pragma unroll
     for (int k = 0; k < UR; ++k)
         if (k * NT + wave * 64 < USLOTS) dma16(urs, uoff, usoff + k * NT * 16, smem + (HSLOTS + k * NT + wave * 64) * 4);
@@ -259,11 +272,20 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         hrange = cstr + (pair ? (unsigned)img : 0u);
     };
     src_begin(p.s0);
+    const bool in2 = KSPLIT && c0 >= p.nchunk0;         // the slice starts inside the second source (virtual concat)
+    if constexpr (KSPLIT) {
+        if (in2) {
+            src_begin(p.s1);
+            hptr += (size_t)(c0 - p.nchunk0) * cstr;
+        } else {
+            hptr += (size_t)c0 * cstr;
+        }
+    }
 
     // halo of chunk ch (absolute index): switch of the source at the virtual concat, HR wave-instructions, advance
 #define W4_HALO_BEGIN(ch)                                                                      \
     do {                                                                                       \
-        if ((ch) == p.nchunk0) {                      /* wave-uniform: switch to the second source (virtual concat) */ \
+        if ((ch) == W4_NCHUNK0) {                     /* wave-uniform: switch to the second source (virtual concat) */ \
             src_begin(p.s1);                                                                   \
             plan(p.s1);                                                                        \
         }                                                                                      \
@@ -286,7 +308,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // first bytes are on their way ~2000 clocks before the last piece is issued.  (Chunk 0 always comes from the first source.)
 #pragma unroll
     for (int k = 0; k < HR; ++k) {
-        plan(p.s0, k, k + 1);
+        if (in2) plan(p.s1, k, k + 1);
+        else plan(p.s0, k, k + 1);
         W4_HALO_PIECE(k, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -300,7 +323,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // The bias rides in the accumulator of transform-domain position (1, 1): A^T has a column of ones there, so A^T M A adds
     // M(1,1) to all 16 outputs of a tile.  That position (p = 3*1 + 1 = 4) belongs to the waves of column half 0, for both
     // cout blocks (their sums for block 1 go to the partner wave in the epilogue): no bias load or add in the epilogue.
-    if (jh == 0) {
+    if (jh == 0 && !KSPLIT) {
         if constexpr (SWP) {
             const int q4 = 4 * (lane_id() >> 4);        // register i = cout 4q + i
             acc[0][4] = *reinterpret_cast<const f32x4 *>(p.bias + ct * 32 + q4);
@@ -327,7 +350,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     asm volatile("" : "+v"(acc[0][4]), "+v"(acc[1][4]));
     __syncthreads();
     // the halo of chunk 1 goes out at once (image 1 has no reader yet); from here on the halo runs two chunks ahead
-    if (p.nchunk > 1) {
+    if (W4_NCHUNK > 1) {
         W4_HALO_BEGIN(1);
 #pragma unroll
         for (int k = 0; k < HR; ++k) W4_HALO_PIECE(k, 1);
@@ -392,8 +415,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         else dot_sums_std();
     };
     if (LEAN && !active) {                              // (the plain variant's register allocation suffers from this branch: -3 %)
-        for (int c = 0; c < p.nchunk; ++c) {
-            const bool more1 = c + 1 < p.nchunk, more2 = c + 2 < p.nchunk;
+        for (int c = 0; c < W4_NCHUNK; ++c) {
+            const bool more1 = c + 1 < W4_NCHUNK, more2 = c + 2 < W4_NCHUNK;
             if (more1) {
 #pragma unroll
                 for (int k = 0; k < UR; ++k) W4_U_PIECE(k, (c + 1) & 1);
@@ -442,8 +465,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     };
     read_patch(0, 0, 30);
 #pragma clang loop unroll(disable)                      // (also keeps hipcc from peeling the last iteration, whose copy spilled 60 registers)
-    for (int c = 0; c < p.nchunk; ++c) {
-        const bool more = c + 1 < p.nchunk, more2 = c + 2 < p.nchunk;
+    for (int c = 0; c < W4_NCHUNK; ++c) {
+        const bool more = c + 1 < W4_NCHUNK, more2 = c + 2 < W4_NCHUNK;
         const int nb = (c + 1) & 1;
         const float *sA = smem + (c & 1) * IMG;
         const float *sB = sA + HSLOTS * 4;
@@ -729,7 +752,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
     const int nb = n + (pair ? bx : 0);                 // pair mode: the tile blocks of column 1 belong to the next clip
     const bool clip_ok = nb < p.N;
-    float *ob = static_cast<float *>(p.out) + (size_t)nb * p.H * p.W * p.Cout + act_off<float>(p.Cout, (long)p.H * p.W, 0, col);
+    // (KSPLIT: raw sums into the partial buffer, pixel-major: pixels are Cout floats apart instead of the 8 of the C8 layout)
+    float *ob = KSPLIT ? p.partial + ((size_t)ksp * p.N + nb) * p.H * p.W * p.Cout + col
+                       : static_cast<float *>(p.out) + (size_t)nb * p.H * p.W * p.Cout + act_off<float>(p.Cout, (long)p.H * p.W, 0, col);
+    const int pstr = KSPLIT ? p.Cout : 8;
     float *pb = (EPI == CONV3X3_RELU_POOL)
                     ? static_cast<float *>(p.pool) + (size_t)nb * Hp * Wp * p.Cout + act_off<float>(p.Cout, (long)Hp * Wp, 0, col)
                     : nullptr;
@@ -740,7 +766,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         float *orow[4], *prow[2];
         if constexpr (INT) {
 #pragma unroll
-            for (int a = 0; a < 4; ++a) orow[a] = ob + ((size_t)(gy0e + a) * p.W + gx0e) * 8;
+            for (int a = 0; a < 4; ++a) orow[a] = ob + ((size_t)(gy0e + a) * p.W + gx0e) * pstr;
             if (EPI == CONV3X3_RELU_POOL) {
 #pragma unroll
                 for (int a = 0; a < 2; ++a) prow[a] = pb + ((size_t)((gy0e >> 1) + a) * Wp + (gx0e >> 1)) * 8;
@@ -803,11 +829,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 const f32x4 o = *reinterpret_cast<const f32x4 *>(xr + (r * 4 + a) * 256);
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
-                    y[a][b] = relu_nan(y[a][b] + o[b]);
+                    y[a][b] = KSPLIT ? y[a][b] + o[b] : relu_nan(y[a][b] + o[b]);
                     if constexpr (INT) {
-                        orow[a][(4 * r + b) * 8] = y[a][b];
+                        orow[a][(4 * r + b) * pstr] = y[a][b];
                     } else {
-                        if (clip_ok && gy + a < p.H && gx + b < p.W) ob[((size_t)(gy + a) * p.W + gx + b) * 8] = y[a][b];
+                        if (clip_ok && gy + a < p.H && gx + b < p.W) ob[((size_t)(gy + a) * p.W + gx + b) * pstr] = y[a][b];
                     }
                 }
             }
@@ -843,7 +869,8 @@ bool wino4_applicable(ConvKind kind, const ConvArgs &a, bool force)
 {
     if (kind != CONV3X3_RELU && kind != CONV3X3_RELU_POOL && kind != CONV3X3_RELU_DOT) return false;
     if (kind == CONV3X3_RELU_DOT && (!a.dotw || !a.dot_out)) return false;
-    if (a.firstw || a.ksplit > 1 || (a.Cout & 31) || a.nchunk < 1) return false;
+    if (a.firstw || (a.Cout & 31) || a.nchunk < 1) return false;
+    if (a.ksplit > 1 && (kind == CONV3X3_RELU_DOT || !a.partial || a.nchunk % a.ksplit || a.ksplit > ADN_MAX_KSPLIT)) return false;
     // images at most 16 pixels wide run in pair mode: a tile covers 32 rows x 16 columns of each of two clips
     const long th = (a.H + REG - 1) / REG, tw = (a.W + REG - 1) / REG;
     const long tiled = wino4_pair_mode(a) ? th * REG * 16 : th * tw * REG * REG;
@@ -873,7 +900,10 @@ hipError_t launch_wino4_conv(ConvKind kind, const ConvArgs &a, hipStream_t st)
         a2.fdTy = make_fastdiv((unsigned)a2.tilesY);
     }
     a2.nwg_total = (int)nwg;
-    const long grid = nwg;
+    const int ks = a.ksplit > 1 ? a.ksplit : 1;
+    a2.nwg_base = (int)nwg;
+    const long grid = nwg * ks;
+    if (grid > 0x7fffffffL) return hipErrorInvalidValue;
     static std::atomic<unsigned long long> attr_mask{0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
@@ -885,12 +915,22 @@ hipError_t launch_wino4_conv(ConvKind kind, const ConvArgs &a, hipStream_t st)
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_conv_f32<CONV3X3_RELU_DOT>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_conv_f32<CONV3X3_RELU, 1>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         if (e1 != hipSuccess) return e1;
         if (e2 != hipSuccess) return e2;
         if (e3 != hipSuccess) return e3;
+        if (e4 != hipSuccess) return e4;
         attr_mask.fetch_or(bit, std::memory_order_release);
     }
     static_assert(8 * (256 * 17 + 32) * sizeof(float) <= LDS_BYTES, "staging of the fused 1x1 epilogue must fit the images");
+    if (ks > 1) {
+        // slices (raw sums, plain variant whatever the layer's epilogue), then sum + bias + ReLU (+ pool)
+        hipLaunchKernelGGL((wino4_conv_f32<CONV3X3_RELU, 1>), dim3((unsigned)grid), dim3(NT), LDS_BYTES, st, a2);
+        hipError_t le = hipGetLastError();
+        if (le != hipSuccess) return le;
+        return launch_wino_reduce(kind, a2, st);
+    }
     if (kind == CONV3X3_RELU_DOT)
         hipLaunchKernelGGL(wino4_conv_f32<CONV3X3_RELU_DOT>, dim3((unsigned)grid), dim3(NT), LDS_BYTES, st, a2);
     else if (kind == CONV3X3_RELU_POOL)

@@ -591,19 +591,7 @@ hipError_t launch_wino_dma_n(ConvKind kind, const ConvArgs &a, hipStream_t st)
                            st, a2);
         le = hipGetLastError();
         if (le != hipSuccess) return le;
-        const long items = kind == CONV3X3_RELU_POOL ? (long)a2.N * ((a2.H + 1) / 2) * ((a2.W + 1) / 2) * (a2.Cout / 4)
-                                                     : (long)a2.N * a2.H * a2.W * (a2.Cout / 4);
-        if (items > 0x7fffffffL * 256L) return hipErrorInvalidValue;
-        const unsigned blocks = (unsigned)((items + 255) / 256);
-        if (kind == CONV3X3_RELU_POOL)
-            hipLaunchKernelGGL(wino_reduce_kernel<CONV3X3_RELU_POOL>, dim3(blocks), dim3(256), 0, st, a2.partial, a2.bias,
-                               static_cast<float *>(a2.out), static_cast<float *>(a2.pool), a2.ksplit, a2.N, a2.H, a2.W,
-                               a2.Cout);
-        else
-            hipLaunchKernelGGL(wino_reduce_kernel<CONV3X3_RELU>, dim3(blocks), dim3(256), 0, st, a2.partial, a2.bias,
-                               static_cast<float *>(a2.out), static_cast<float *>(nullptr), a2.ksplit, a2.N, a2.H, a2.W,
-                               a2.Cout);
-        return hipGetLastError();
+        return launch_wino_reduce(kind, a2, st);
     }
     if (a2.firstw) {
         // fused first layer: down1's second conv (+pool) fed by the network input
@@ -639,6 +627,24 @@ hipError_t launch_wino_dma_n(ConvKind kind, const ConvArgs &a, hipStream_t st)
 }
 
 }  // namespace
+
+// second launch of a split-K 3x3 layer (either Winograd kernel): a.partial [split][N][H][W][Cout] -> a.out (+ a.pool)
+hipError_t launch_wino_reduce(ConvKind kind, const ConvArgs &a, hipStream_t st)
+{
+    if (a.ksplit < 2 || a.ksplit > ADN_MAX_KSPLIT || !a.partial || (a.Cout & 3) || (kind != CONV3X3_RELU && kind != CONV3X3_RELU_POOL))
+        return hipErrorInvalidValue;
+    const long items = kind == CONV3X3_RELU_POOL ? (long)a.N * ((a.H + 1) / 2) * ((a.W + 1) / 2) * (a.Cout / 4)
+                                                 : (long)a.N * a.H * a.W * (a.Cout / 4);
+    if (items <= 0 || items > 0x7fffffffL * 256L) return hipErrorInvalidValue;
+    const unsigned blocks = (unsigned)((items + 255) / 256);
+    if (kind == CONV3X3_RELU_POOL)
+        hipLaunchKernelGGL(wino_reduce_kernel<CONV3X3_RELU_POOL>, dim3(blocks), dim3(256), 0, st, a.partial, a.bias,
+                           static_cast<float *>(a.out), static_cast<float *>(a.pool), a.ksplit, a.N, a.H, a.W, a.Cout);
+    else
+        hipLaunchKernelGGL(wino_reduce_kernel<CONV3X3_RELU>, dim3(blocks), dim3(256), 0, st, a.partial, a.bias,
+                           static_cast<float *>(a.out), static_cast<float *>(nullptr), a.ksplit, a.N, a.H, a.W, a.Cout);
+    return hipGetLastError();
+}
 
 long wino_workgroups(const ConvArgs &a)
 {
