@@ -39,7 +39,7 @@ def test_host_only_entry_points_and_errors():
     one = need.value
     assert L.adn_unet_workspace_bytes(None, 4, 513, 256, ctypes.byref(need)) == 0
     # activations scale with N; the split-K scratch of the deep layers (small batches only) does not
-    assert 3.5 * one <= need.value <= 4 * one and one > 513 * 256 * 64 * 4 * 2
+    assert 3.3 * one <= need.value <= 4 * one and one > 513 * 256 * 64 * 4 * 2
     assert L.adn_unet_workspace_bytes(None, 1, 8, 256, ctypes.byref(need)) == 1      # ADN_ERR_INVALID
     assert b"F,T>=16" in L.adn_last_error()
     nfr = ctypes.c_long()
