@@ -94,7 +94,7 @@ ADN_API int adn_unet_create_general(adn_unet **handle, int device, const float *
 ADN_API int adn_unet_channels(const adn_unet *handle, int *in_channels, int *num_classes);
 /* Kernel choice by the launch's grid.  Default (on = 0): fp32 3x3 layers run F(4x4,3x3) where its 32x32-pixel tiles fill the chip,
  * F(2x2,3x3) otherwise; layers whose grid is still too small (one clip ... a dozen, at the deep levels) have their K loop cut over
- * up to 8 workgroups + a reduce launch -- fp32 3x3 layers, fp32 transposed convolutions, fp16 3x3 layers.  Fastest at every batch
+ * up to 8 workgroups + a reduce launch -- fp32 3x3 layers (either Winograd form), fp32 transposed convolutions, fp16 3x3 layers.  Fastest at every batch
  * size, but the same clip computed alone and inside a large batch then differs in the last bits (fp32: both within 1e-4 of the
  * reference; fp16: within 5e-3 of each other, both within 1e-2 of the reference).
  * on = 1: one kernel per layer chosen by the layer's geometry alone -- a clip's result is bit-identical whatever batch it is
