@@ -126,3 +126,28 @@ def test_images_beyond_one_buffer_descriptor(dev, weights_np, shape, dtype, monk
     del y, x
     m._workspace = None
     torch.cuda.empty_cache()
+
+
+AGREE_SHAPES = [(1, 16, 16), (1, 33, 47), (2, 64, 80), (1, 100, 300), (3, 129, 65), (1, 257, 188), (1, 513, 256), (5, 257, 188),
+                (16, 256, 64), (1, 1025, 16), (7, 48, 1040), (1, 40, 2000), (2, 513, 256), (4, 300, 200)]
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 2e-5), ("f16", 5e-3)])
+def test_automatic_and_pinned_kernel_choice_agree(dev, weights_np, dtype, tol):
+    """The automatic choice (small grids: finer tiles, K loops cut over several workgroups in four kernel families + reduce launches)
+    against one kernel per layer (set_batch_invariant): the same network to the last bits of fp32 (2e-5 of max|y|) / of fp16 storage
+    (5e-3), on shapes from one tile to the reference's own batches (5 x 257x188, 16 x 256x64) -- every slice bound, concat switch
+    and partial-buffer layout is crossed by some shape here."""
+    from audiodenoiser_amd.weights import make_input
+    auto = _net(weights_np, dev, dtype)
+    pinned = _net(weights_np, dev, dtype).set_batch_invariant(True)
+    worst = 0.0
+    for n, f, t in AGREE_SHAPES:
+        x = torch.from_numpy(make_input(300 + f, n, f, t)).to(dev)
+        with torch.no_grad():
+            ya, yp = auto(x), pinned(x)
+        assert bool(torch.isfinite(ya).all()) and ya.shape == yp.shape
+        err = float((ya - yp).abs().max() / yp.abs().max().clamp_min(1e-30))
+        worst = max(worst, err)
+        assert err <= tol, (dtype, n, f, t, err)
+    print(f"automatic vs pinned kernel choice, {dtype}: worst {worst:.2e} of max|y| (bound {tol})")
