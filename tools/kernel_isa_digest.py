@@ -38,7 +38,7 @@ def digests(text):
         if name:
             ins = line.split(";")[0].rstrip()
             if ins.strip() and not ins.strip().startswith("."):          # instructions only (labels kept: they start with .L -> dropped, branch targets stay in the text)
-                body.append(ins.strip())
+                body.append(re.sub(r"\.LBB\d+_", ".LBB_", ins.strip()))      # (a label carries its function's index in the file: not code)
     return out
 
 
