@@ -356,7 +356,7 @@ struct Plan {
 int convt_ks(int N, int H, int W, int Cin, int Cout)
 {
     const long nwg = (long)N * ((H + 7) / 8) * ((W + 15) / 16) * (4 * Cout / 128);
-    return adn::convt_ksplit(nwg, Cin / 16);
+    return adn::convt_ksplit(nwg, Cin / 16, (size_t)N * (2 * H) * (2 * W) * Cout);
 }
 
 bool make_plan(int N, int F, int T, bool f16, Plan &p)

@@ -162,14 +162,25 @@ inline int wino4_ksplit(long grid, int nchunk)
     return ks;
 }
 
-// Number of K splits for a transposed convolution (fp32 split-bf16 form) launched as `nwg` workgroups of `nchunk` 16-channel chunks:
-// one clip at the two deepest levels runs 64 / 128 workgroups through 64 / 32 chunks of ~1 us each (latency-bound: a chunk is 12 KB of
-// weights and 32 MFMAs per wave); cut until the grid has a workgroup per CU, never below 8 chunks per slice.
-inline int convt_ksplit(long nwg, int nchunk)
+// Number of K splits for a transposed convolution (fp32 split-bf16 form) launched as `nwg` workgroups of `nchunk` 16-channel chunks
+// whose output is `out_floats` floats.  A chunk is 12 KB of weights and 32 MFMAs per wave: latency-bound at ~1.3 us whatever the
+// occupancy, so one clip at the two deepest levels (64 / 128 workgroups, 64 / 32 chunks) is cut over several workgroups.  Chosen by
+// the measured times (profiles/r05_b1_timelines.txt), in microseconds: 8 + 1.28 per chunk and round of 768 workgroups (three per
+// CU); a reduce launch 4 + (copies + 1) x output bytes at 8 TB/s; a slice keeps >= 8 chunks.
+inline int convt_ksplit(long nwg, int nchunk, size_t out_floats)
 {
-    int ks = 1;
-    while (ks < 8 && nwg * ks * 2 <= 256 && nchunk % (ks * 2) == 0 && nchunk / (ks * 2) >= 8) ks *= 2;
-    return ks;
+    const double out_mb = (double)out_floats * 4.0 * 1e-6;
+    int best = 1;
+    double tbest = 0.0;
+    for (int ks = 1; ks <= ADN_MAX_KSPLIT; ks *= 2) {
+        if (nchunk % ks || (ks > 1 && nchunk / ks < 8)) break;
+        const double t = 8.0 + 1.28 * (nchunk / ks) * (double)((nwg * ks + 767) / 768) + (ks > 1 ? 4.0 + (ks + 1) * out_mb / 8.0 : 0.0);
+        if (ks == 1 || t < tbest - 0.5) {
+            best = ks;
+            tbest = t;
+        }
+    }
+    return best;
 }
 
 // Number of K splits for an fp16 3x3 layer launched as `nwg` workgroups (32x16 pixels x 64 couts) of `nchunk` 16-channel chunks:

@@ -1110,7 +1110,10 @@ hipError_t launch_conv_first(const float *x, const float *w9x64, const float *bi
     // column tiles: the widest window that fits the CU's LDS, Cin * (cols + 2) <= 4096 floats per window row (whole rows up to
     // 4094 frames of one plane: one tile, as before); wider images are cut into equal tiles
     const int max_cols = 4096 / Cin - 2;
-    const int tiles_x = (W + max_cols - 1) / max_cols;
+    int tiles_x = (W + max_cols - 1) / max_cols;
+    // small grids (a few clips): narrower tiles, down to 64 columns, until the launch has two workgroups per CU -- the arithmetic of a
+    // pixel does not depend on the tile it falls into
+    while ((long)N * tiles_y * tiles_x < 512 && (W + 2 * tiles_x - 1) / (2 * tiles_x) >= 64) tiles_x *= 2;
     const int cols = (W + tiles_x - 1) / tiles_x;
     const long blocks = (long)N * tiles_y * tiles_x;
     const size_t lds = (size_t)Cin * (FIRST_ROWS + 2) * (cols + 2) * sizeof(float);
